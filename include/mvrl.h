@@ -1,0 +1,228 @@
+/*
+ * mvrl.h - C ABI of libmvrl.so: MI355X-native vectorised marine-vehicle environments.
+ *
+ * This is the drop-in boundary for the reference's environment hot path.  Every entry point
+ * cites the reference interface it replaces (paths relative to the reference checkout;
+ * "6DoF.py" = dynamicsModel_BlueROV2_Heavy_6DoF.py, "3DoF.py" = dynamicsModel_BlueROV2_Heavy_3DoF.py,
+ * "tag/" = tag_00_Dec2023_simpleControlTurbulence/).
+ *
+ * Conventions
+ *   - plain C symbols, plain pointers and sizes, no C++/torch types;
+ *   - every function returns 0 on success or a negative MVRL_E* code; the message is
+ *     available through mvrl_last_error(); no exception crosses the ABI;
+ *   - one handle = one device, one internal HIP stream, one host thread at a time;
+ *   - host-pointer entry points (`mvrl_step`, `mvrl_reset`, ...) are synchronous on return;
+ *     `*_dev` entry points take DEVICE pointers, enqueue on the given stream (NULL = the
+ *     handle's own stream) and return after enqueue;
+ *   - actions / observations are row-major [n_envs, dim] float32 at the ABI (what the
+ *     reference's Gym API and SB3's VecEnv exchange); internal state is SoA in HBM;
+ *   - the library owns all device buffers; it never retains a caller pointer past a call.
+ *
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with
+ * MVRL_ENODEV.
+ */
+#ifndef MVRL_H
+#define MVRL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVRL_ABI_VERSION 1
+
+/* ---- models (which reference environment the handle replaces) ------------------------------ */
+#define MVRL_MODEL_AUV 0  /* AuvEnv, explicit Euler + turbulence current   tag/verySimpleAuv.py:76-416 */
+#define MVRL_MODEL_ROV3 1 /* BlueROV2Heavy3DoFEnv                           3DoF.py:375-514             */
+#define MVRL_MODEL_ROV6 2 /* BlueROV2Heavy6DoFEnv                           6DoF.py:445-594             */
+
+/* ---- where the PID sits relative to the integrator ---------------------------------------- */
+#define MVRL_CTRL_FAITHFUL 0 /* PID inside the RHS, evaluated (and mutated) at every RK stage - as 6DoF.py:418 */
+#define MVRL_CTRL_ZOH 1      /* PID + allocation once per sub-step, thruster rpm held over the stages          */
+
+/* ---- error codes --------------------------------------------------------------------------- */
+#define MVRL_OK 0
+#define MVRL_EINVAL (-1)  /* bad argument / configuration     */
+#define MVRL_ENODEV (-2)  /* no usable HIP device             */
+#define MVRL_ENOMEM (-3)  /* device or host allocation failed */
+#define MVRL_EHIP (-4)    /* a HIP runtime call failed        */
+#define MVRL_ESTATE (-5)  /* call sequence error (e.g. step_wait without step_async) */
+
+/* 6-DoF vehicle + PID constants.  Values are produced on the host in fp64 from the reference's
+ * literals (6DoF.py:83-218 vehicle, :43-53 PID) - see marinevehiclereinforcementlearning_amd/params.py -
+ * and narrowed to fp32 when uploaded. Matrices are row-major. */
+typedef struct mvrl_rov6_params {
+    double m;             /* 11.4                                  6DoF.py:88  */
+    double length;        /* 0.457                                 6DoF.py:90  */
+    double cg[3];         /* [0,0,0.05]                            6DoF.py:95  */
+    double cb[3];         /* [0,0,0]                               6DoF.py:94  */
+    double inertia[9];    /* 0.16*I3                               6DoF.py:97  */
+    double weight;        /* m*9.81                                6DoF.py:372 */
+    double buoyancy;      /* dispVol*rho*9.81                      6DoF.py:373 */
+    double added[6];      /* Xudot,Yvdot,Zwdot,Kpdot,Mqdot,Nrdot (Coriolis Ca)  6DoF.py:334-341 */
+    double minv[36];      /* inverse of M = Mrb + Ma               6DoF.py:286-299,428 */
+    double mass[36];      /* M itself (returned by forceModel)     6DoF.py:299 */
+    double dlin[36];      /* Dl  = -[linear coeffs]                6DoF.py:345-352 */
+    double dquad[36];     /* -[quadratic coeffs]; entry (i,j) multiplies |nu_j|  6DoF.py:354-368 */
+    double alloc[48];     /* A    6x8                              resources.py:27-32 */
+    double alloc_inv[48]; /* Ainv 8x6 = pinv(A)                    resources.py:33 */
+    double thrust_k;      /* rho*D^4*Kt : F = thrust_k*(rpm/60)^2*sign(rpm)   6DoF.py:228,235 */
+    double rpm_max;       /* 3500                                  6DoF.py:272 */
+    double rpm_deadband;  /* 300                                   6DoF.py:273 */
+    double kp[6], ki[6], kd[6], windup[6], umax[6]; /* 6DoF.py:46-53 */
+    double act_scale[6];  /* [2L,2L,2L,pi/4,pi/4,pi/4]             6DoF.py:545-551 */
+    double obs_pos_scale; /* 3L                                    6DoF.py:472 */
+    double obs_ang_scale; /* pi/4                                  6DoF.py:480 */
+} mvrl_rov6_params;
+
+/* 3-DoF vehicle (PID inlined in derivs) - 3DoF.py:26-126, :141-157 */
+typedef struct mvrl_rov3_params {
+    double m, length;
+    double cg[3];
+    double izz;
+    double added[3];       /* Xudot, Yvdot, Nrdot                   3DoF.py:58-60 */
+    double minv[9];        /* inverse of M                          3DoF.py:198-206,283 */
+    double mass[9];
+    double dlin[9];        /* 3DoF.py:225-229 */
+    double dquad[9];       /* 3DoF.py:231-239 ; entry (i,j) multiplies [|uRel|,|vRel|,|r|][j] */
+    double alloc_inv[12];  /* Ainv 4x3                              3DoF.py:104-112 */
+    double thrust_k;       /* rho*D^4*Kt                            3DoF.py:118 */
+    double rpm_max, rpm_deadband;
+    double cos_alpha, sin_alpha; /* 45 deg                           3DoF.py:90 */
+    double yaw_arm;        /* sqrt(l_x^2+l_y^2)                     3DoF.py:263 */
+    double jet_area_k;     /* 0.5*rho*pi*D^2                        3DoF.py:121 */
+    double jet_c1, jet_k1, jet_c2, jet_k2; /* 0.56599,7.60891,0.05654,0.89679  3DoF.py:122-123 */
+    double jet_drag_k;     /* 0.5*rho*dispVol^(2/3)                 3DoF.py:124 */
+    double kp[3], ki[3], kd[3], windup[3], umax[3]; /* 3DoF.py:142-154 */
+    double act_scale[3];   /* [2L,2L,pi/4]                          3DoF.py:469-471 */
+    double obs_pos_scale, obs_ang_scale;
+} mvrl_rov3_params;
+
+/* Simplified AUV - tag/verySimpleAuv.py:106-127 */
+typedef struct mvrl_auv_params {
+    double m, izz;
+    double xuu, yvv, nrr, xu, yv, nr;
+    double max_force, max_moment;
+    double x_min, x_max, y_min, y_max;   /* :106-107 */
+    double noise_mag_coeffs, noise_mag_actuation; /* :124-125 */
+    int32_t stop_on_bounds;              /* :88 */
+    int32_t _pad;
+} mvrl_auv_params;
+
+/* Turbulence table as produced by ReconstructedFlow.scale (tag/flowGenerator.py:53-95):
+ * float32 [n_t][n_y][n_x][2] = (u, v), spacing dt/dx/dy AFTER scaling; the interpolation ignores the
+ * origin (as the reference does, flowGenerator.py:118-120). */
+typedef struct mvrl_flow_desc {
+    int32_t n_t, n_y, n_x, _pad;
+    double dt, dx, dy;
+} mvrl_flow_desc;
+
+typedef struct mvrl_config {
+    int32_t abi_version;    /* MVRL_ABI_VERSION */
+    int32_t model;          /* MVRL_MODEL_* */
+    int32_t device;         /* HIP device ordinal */
+    int32_t n_substeps;     /* RK4 sub-steps per env step (3/6-DoF; >= 1).  AUV: ignored (Euler) */
+    int64_t n_envs;         /* environments owned by this handle (this shard) */
+    int64_t env_offset;     /* global index of the first env: RNG streams are keyed by the GLOBAL id */
+    double dt;              /* env step (6DoF.py:446 dt=0.2 ; verySimpleAuv.py:77 dt=0.02) */
+    int32_t max_steps;      /* episode length (250) */
+    int32_t control_mode;   /* MVRL_CTRL_* (3/6-DoF) */
+    int32_t fixed_setpoint; /* 1: ignore actions, hold the reset set-point (the reference's fixedSp, 6DoF.py:536-541) */
+    int32_t auto_reset;     /* 1: SB3 VecEnv semantics - done lanes are re-initialised inside step */
+    uint64_t seed;          /* counter-based RNG key for resets without explicit initial values */
+    int32_t use_flow;       /* 1: sample the turbulence table each step (AUV: as the reference; 3/6-DoF: SURVEY 9.5) */
+    int32_t _pad;
+    mvrl_rov6_params rov6;
+    mvrl_rov3_params rov3;
+    mvrl_auv_params auv;
+} mvrl_config;
+
+typedef struct mvrl_handle mvrl_handle;
+
+/* ---- introspection ------------------------------------------------------------------------- */
+int mvrl_abi_version(void);
+/* number of visible HIP devices (0 when none; never fails) */
+int mvrl_device_count(void);
+/* Last error message of `h`, or of the last failed call without a handle when h == NULL. */
+const char* mvrl_last_error(const mvrl_handle* h);
+/* dims for a model: returns 0 / MVRL_EINVAL */
+int mvrl_model_dims(int32_t model, int32_t* act_dim, int32_t* obs_dim, int32_t* init_dim, int32_t* state_words);
+
+/* ---- lifetime: replaces Env.__init__ (6DoF.py:446-465, 3DoF.py:376-395, verySimpleAuv.py:77-145) ---- */
+int mvrl_create(const mvrl_config* cfg, mvrl_handle** out);
+void mvrl_destroy(mvrl_handle* h);
+
+/* Upload the scaled turbulence table (host float32 [n_t][n_y][n_x][2]).
+ * Replaces the table held by ReconstructedFlow after scale() (flowGenerator.py:76-95). */
+int mvrl_set_flow(mvrl_handle* h, const float* table_host, const mvrl_flow_desc* desc);
+/* Same, table already resident on the handle's device (not copied; caller keeps it alive). */
+int mvrl_set_flow_dev(mvrl_handle* h, const float* table_dev, const mvrl_flow_desc* desc);
+
+/* ---- reset: replaces Env.reset (6DoF.py:485-529, 3DoF.py:411-453, verySimpleAuv.py:216-262) ----------
+ * mask : n_envs bytes, non-zero = reset this env; NULL = all.
+ * init : [n_envs, init_dim] explicit initial values, NULL = draw from the counter-based RNG.
+ *        ROV6: wp0(3) wp1(3) target angles(3)   (reset(initialSetpoint=sp) == wp0=wp1=sp[:3], angles=sp[3:])
+ *        ROV3: wp0(2) wp1(2) target heading(1)
+ *        AUV : x y heading headingTarget flowTimeOffset  mMult IMult XuuMult YvvMult NrrMult XuMult YvMult NrMult
+ *              XactMult YactMult NactMult   (fixedInitialValues + the multipliers of verySimpleAuv.py:222-229,245)
+ * obs  : [n_envs, obs_dim] out (rows of envs that were not reset are left untouched); may be NULL. */
+int mvrl_reset(mvrl_handle* h, const uint8_t* mask, const float* init, float* obs);
+int mvrl_reset_dev(mvrl_handle* h, const uint8_t* mask_dev, const float* init_dev, float* obs_dev, void* stream);
+
+/* ---- step: replaces Env.step (6DoF.py:531-594, 3DoF.py:455-514, verySimpleAuv.py:264-410) -------------
+ * and SB3 VecEnv.step_async/step_wait (called at tag/main_00_sbl.py:145-161 through agent.learn).
+ * actions [n_envs, act_dim] f32 ; obs [n_envs, obs_dim] f32 ; reward [n_envs] f32 ; done [n_envs] u8. */
+int mvrl_step(mvrl_handle* h, const float* actions, float* obs, float* reward, uint8_t* done);
+int mvrl_step_async(mvrl_handle* h, const float* actions);
+int mvrl_step_wait(mvrl_handle* h, float* obs, float* reward, uint8_t* done);
+int mvrl_step_dev(mvrl_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
+                  void* stream);
+
+/* Observation of the step on which an env finished (SB3 infos[i]["terminal_observation"]); rows of envs
+ * that did not finish on the last step are unspecified.  Only meaningful with auto_reset = 1. */
+int mvrl_get_terminal_obs(mvrl_handle* h, float* obs);
+int mvrl_get_terminal_obs_dev(mvrl_handle* h, float* obs_dev, void* stream);
+
+/* ---- raw state (checkpoint / parity tests): SoA [state_words][n_envs] float32 ------------------------ */
+int mvrl_get_state(mvrl_handle* h, float* buf, size_t n_floats);
+int mvrl_set_state(mvrl_handle* h, const float* buf, size_t n_floats);
+
+/* Per-step side outputs the reference keeps in timeHistory (6DoF.py:578-587: F0..F5, u0..u7; 3DoF: F0..F2,u0..u3;
+ * verySimpleAuv.py:389-403: Fx,Fy,N,u_current,v_current,rmsAc,r0..r4).  Enable BEFORE stepping;
+ * aux row = [n_envs, aux_dim] f32 with aux_dim = 14 (ROV6) / 7 (ROV3) / 11 (AUV). */
+int mvrl_enable_aux(mvrl_handle* h, int32_t enable);
+int mvrl_get_aux(mvrl_handle* h, float* aux);
+
+/* ---- stand-alone turbulence-field operators ----------------------------------------------------------- */
+/* ReconstructedFlow.interp (flowGenerator.py:97-136) for n query points; table is host f32
+ * [n_t][n_y][n_x][n_comp]; out [n, n_comp]. */
+int mvrl_flow_interp(int32_t device, const float* table_host, const mvrl_flow_desc* desc, int32_t n_comp,
+                     const float* t, const float* x, const float* y, int64_t n, float* out);
+/* ReconstructedFlow.__init__ + scale (flowGenerator.py:19-23, 76-92): out[t,j,i,c] =
+ * affine_c( sum_k Re(modes[j,i,c,k]*coeffs[k,t]) + ltm[j,i,c] ).  modes_re/modes_im [n_y*n_x*3, K],
+ * coeffs_re/coeffs_im [K, n_t], ltm [n_y*n_x*3]; scale_mul/scale_add [3]; out host f32 [n_t, n_y*n_x*3]. */
+int mvrl_flow_reconstruct(int32_t device, const float* modes_re, const float* modes_im, const float* coeffs_re,
+                          const float* coeffs_im, const float* ltm, int32_t n_space3, int32_t n_modes, int32_t n_t,
+                          const float* scale_mul, const float* scale_add, float* out);
+
+/* ---- benchmark helpers -------------------------------------------------------------------------------- */
+/* Fill a DEVICE buffer with uniform(lo,hi) f32 from the counter-based generator (key seed, stream `counter`). */
+int mvrl_fill_uniform_dev(mvrl_handle* h, float* dst_dev, int64_t n, uint64_t seed, uint64_t counter, float lo,
+                          float hi, void* stream);
+/* HIP-event timing of step kernels launched through mvrl_step_dev on `stream`:
+ * begin records an event, end records another, synchronises it and returns elapsed ms and launch count. */
+int mvrl_timing_begin(mvrl_handle* h, void* stream);
+int mvrl_timing_end(mvrl_handle* h, void* stream, float* elapsed_ms, int64_t* n_launches);
+/* device allocation helpers so that torch-free callers can own device buffers */
+int mvrl_dev_alloc(mvrl_handle* h, size_t bytes, void** out_dev);
+int mvrl_dev_free(mvrl_handle* h, void* dev);
+int mvrl_dev_upload(mvrl_handle* h, void* dst_dev, const void* src_host, size_t bytes);
+int mvrl_dev_download(mvrl_handle* h, void* dst_host, const void* src_dev, size_t bytes);
+int mvrl_synchronize(mvrl_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVRL_H */
