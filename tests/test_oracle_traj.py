@@ -1,0 +1,90 @@
+"""CPU oracle vs golden TRAJECTORIES produced by the imported reference:
+  G9  - reference derivs under the fixed-step RK4 harness (faithful / ZOH / fixed set-point)
+  G10 - the reference's real env.step (scipy RK45), incl. BASELINE config 1 (3-DoF, 1 env, 1000 random steps)
+"""
+import numpy as np
+import pytest
+
+from .conftest import golden, max_scaled_err
+from marinevehiclereinforcementlearning_amd import params as P
+
+
+def run_against(oracle_mod, g, dof, integrator, n_sub=4, mode=P.CTRL_FAITHFUL, max_len=None, horizon=None):
+    n_env, n_steps = g["actions"].shape[:2]
+    if max_len:
+        n_steps = min(n_steps, max_len)
+    env = oracle_mod.OracleRovEnv(dof, n_env, "f64", dt=float(g["dt"]), n_substeps=n_sub, integrator=integrator,
+                                  control_mode=mode, fixed_setpoint=bool(g["fixedSp"]), max_steps=10 ** 9)
+    npos = 3 if dof == 6 else 2
+    init = np.concatenate([g["path"].reshape(n_env, 2 * npos), g["sp0"][:, npos:]], axis=1)
+    obs0 = env.reset(init)
+    err = dict(state=0.0, obs=max_scaled_err(obs0, g["obs"][:, 0]), pid=0.0, rpm=0.0, per_step=[])
+    nfev = []
+    for s in range(n_steps):
+        obs, rew, done = env.step(g["actions"][:, s])
+        err["per_step"].append(max_scaled_err(env.y, g["states"][:, s + 1]))
+        if horizon is not None and s >= horizon:
+            nfev.append(env.nfev.copy())
+            continue
+        err["state"] = max(err["state"], max_scaled_err(env.y, g["states"][:, s + 1]))
+        err["obs"] = max(err["obs"], max_scaled_err(obs, g["obs"][:, s + 1]))
+        err["pid"] = max(err["pid"], max_scaled_err(env.eold, g["eOld"][:, s]), max_scaled_err(env.eint, g["eInt"][:, s]))
+        err["rpm"] = max(err["rpm"], max_scaled_err(env.rpm / 3500., g["rpm"][:, s] / 3500.))
+        assert np.all(rew == 0) and not done.any()
+        nfev.append(env.nfev.copy())
+    return err, np.array(nfev).T
+
+
+@pytest.mark.parametrize("name,dof,n_sub,mode", [
+    ("g09_rk4_6dof_faithful_nsub4.npz", 6, 4, P.CTRL_FAITHFUL),
+    ("g09_rk4_6dof_faithful_nsub8.npz", 6, 8, P.CTRL_FAITHFUL),
+    ("g09_rk4_6dof_faithful_nsub2.npz", 6, 2, P.CTRL_FAITHFUL),
+    ("g09_rk4_6dof_zoh_nsub4.npz", 6, 4, P.CTRL_ZOH),
+    ("g09_rk4_6dof_fixedsp_nsub4.npz", 6, 4, P.CTRL_FAITHFUL),
+    ("g09_rk4_3dof_faithful_nsub4.npz", 3, 4, P.CTRL_FAITHFUL),
+    ("g09_rk4_3dof_faithful_nsub8.npz", 3, 8, P.CTRL_FAITHFUL),
+    ("g09_rk4_3dof_fixedsp_nsub4.npz", 3, 4, P.CTRL_FAITHFUL),
+])
+def test_rk4_harness_trajectories(oracle_mod, name, dof, n_sub, mode):
+    g = golden(name)
+    assert int(g["n_sub"]) == n_sub
+    err, _ = run_against(oracle_mod, g, dof, "rk4", n_sub, mode)
+    # fp64 restatement vs fp64 reference: the (e-eOld)/1e-9 derivative amplifies last-bit differences by 1e9,
+    # but the saturating clamps swallow almost all of it.
+    assert err["state"] < 1e-9, err
+    assert err["obs"] < 1e-9, err
+    assert err["pid"] < 1e-9, err
+
+
+@pytest.mark.parametrize("name,dof", [("g10_envstep_6dof_random.npz", 6), ("g10_envstep_6dof_fixedsp.npz", 6),
+                                      ("g10_envstep_3dof_fixedsp.npz", 3)])
+def test_envstep_rk45_trajectories(oracle_mod, name, dof):
+    """The oracle's scipy-RK45-faithful driver reproduces the reference's real env.step."""
+    g = golden(name)
+    horizon = None
+    if "states_twin" in g.files:
+        # The reference's own reproducibility horizon: the same reference run with the set-point moved by one
+        # ulp.  Parked at the set-point, the PID derivative (e-eOld)/1e-9 amplifies round-off chaotically (3-DoF:
+        # the twin separates after ~20 steps); parity is asserted up to that horizon, boundedness after it.
+        twin = np.abs(g["states"] - g["states_twin"]).max(axis=(0, 2))
+        if (twin > 1e-10).any():
+            horizon = max(1, int(np.argmax(twin > 1e-10)) - 4)
+    err, nfev = run_against(oracle_mod, g, dof, "rk45", horizon=horizon)
+    assert err["state"] < 1e-8, (err["state"], horizon)
+    assert err["obs"] < 1e-8, err["obs"]
+    h = nfev.shape[1] if horizon is None else horizon
+    # identical accept/reject sequence <=> identical RHS call count per step
+    assert np.array_equal(nfev[:, :h], g["ncalls"][:, :h]), (nfev[:, :5], g["ncalls"][:, :5])
+    if horizon is not None:
+        assert horizon >= 12
+        twin_max = float(np.abs(g["states"] - g["states_twin"]).max())
+        assert max(err["per_step"]) < 10 * twin_max + 1e-6, (max(err["per_step"]), twin_max)
+
+
+def test_config1_3dof_1000_random_steps(oracle_mod):
+    """BASELINE.json configs[0]: 3-DoF, 1 env, random actions, 1000-step rollout on the reference CPU path."""
+    g = golden("g10_envstep_3dof_random1000.npz")
+    err, nfev = run_against(oracle_mod, g, 3, "rk45")
+    same_calls = float(np.mean(nfev == g["ncalls"]))
+    assert err["state"] < 1e-7, (err, same_calls)
+    assert same_calls > 0.999, same_calls
