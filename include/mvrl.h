@@ -149,6 +149,13 @@ int mvrl_device_count(void);
 const char* mvrl_last_error(const mvrl_handle* h);
 /* dims for a model: returns 0 / MVRL_EINVAL */
 int mvrl_model_dims(int32_t model, int32_t* act_dim, int32_t* obs_dim, int32_t* init_dim, int32_t* state_words);
+/* width of one row of the aux side outputs (see mvrl_enable_aux), or MVRL_EINVAL */
+int mvrl_aux_dim(int32_t model);
+/* Which kernel flavour the handle dispatches to, e.g. "rov6/baked/faithful+flow":
+ *   baked   - runtime constants equal the reference's defaults bit-for-bit -> literals in the instruction stream
+ *   sym     - BlueROV2-Heavy structure (sparse, sign-symmetric thruster layout), constants read at run time
+ *   generic - arbitrary constants, dense matrices */
+const char* mvrl_variant(const mvrl_handle* h);
 
 /* ---- lifetime: replaces Env.__init__ (6DoF.py:446-465, 3DoF.py:376-395, verySimpleAuv.py:77-145) ---- */
 int mvrl_create(const mvrl_config* cfg, mvrl_handle** out);

@@ -1,0 +1,273 @@
+"""ctypes binding of libmvrl.so (include/mvrl.h) - the only door between Python and the HIP kernels.
+
+The library is loaded lazily on first use.  If it has not been built, or no HIP device is present, the call
+raises: there is deliberately no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import params as P
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmvrl.so")
+
+_lib = None
+
+ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "EHIP", -5: "ESTATE"}
+
+# every symbol include/mvrl.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = [
+    "mvrl_abi_version", "mvrl_device_count", "mvrl_last_error", "mvrl_model_dims", "mvrl_aux_dim", "mvrl_variant",
+    "mvrl_create", "mvrl_destroy", "mvrl_set_flow", "mvrl_set_flow_dev", "mvrl_reset", "mvrl_reset_dev", "mvrl_step",
+    "mvrl_step_async", "mvrl_step_wait", "mvrl_step_dev", "mvrl_get_terminal_obs", "mvrl_get_terminal_obs_dev",
+    "mvrl_get_state", "mvrl_set_state", "mvrl_enable_aux", "mvrl_get_aux", "mvrl_flow_interp", "mvrl_flow_reconstruct",
+    "mvrl_fill_uniform_dev", "mvrl_timing_begin", "mvrl_timing_end", "mvrl_dev_alloc", "mvrl_dev_free",
+    "mvrl_dev_upload", "mvrl_dev_download", "mvrl_synchronize",
+]
+
+
+class MvrlError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """dlopen libmvrl.so and declare the prototypes.  Raises MvrlError if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("MVRL_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise MvrlError(f"{path} not found - build it with `python -m marinevehiclereinforcementlearning_amd.build` "
+                        "(needs hipcc; there is no CPU fallback)")
+    lib = C.CDLL(path)
+    vp, i32, i64, u64, fp = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+    lib.mvrl_abi_version.restype = C.c_int
+    lib.mvrl_device_count.restype = C.c_int
+    lib.mvrl_last_error.restype = C.c_char_p
+    lib.mvrl_last_error.argtypes = [vp]
+    lib.mvrl_variant.restype = C.c_char_p
+    lib.mvrl_variant.argtypes = [vp]
+    lib.mvrl_model_dims.argtypes = [i32] + [C.POINTER(i32)] * 4
+    lib.mvrl_aux_dim.argtypes = [i32]
+    lib.mvrl_create.argtypes = [C.POINTER(P.Config), C.POINTER(vp)]
+    lib.mvrl_destroy.argtypes = [vp]
+    lib.mvrl_destroy.restype = None
+    lib.mvrl_set_flow.argtypes = [vp, vp, C.POINTER(P.FlowDesc)]
+    lib.mvrl_set_flow_dev.argtypes = [vp, vp, C.POINTER(P.FlowDesc)]
+    lib.mvrl_reset.argtypes = [vp, vp, vp, vp]
+    lib.mvrl_reset_dev.argtypes = [vp, vp, vp, vp, vp]
+    lib.mvrl_step.argtypes = [vp, vp, vp, vp, vp]
+    lib.mvrl_step_async.argtypes = [vp, vp]
+    lib.mvrl_step_wait.argtypes = [vp, vp, vp, vp]
+    lib.mvrl_step_dev.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mvrl_get_terminal_obs.argtypes = [vp, vp]
+    lib.mvrl_get_terminal_obs_dev.argtypes = [vp, vp, vp]
+    lib.mvrl_get_state.argtypes = [vp, vp, C.c_size_t]
+    lib.mvrl_set_state.argtypes = [vp, vp, C.c_size_t]
+    lib.mvrl_enable_aux.argtypes = [vp, i32]
+    lib.mvrl_get_aux.argtypes = [vp, vp]
+    lib.mvrl_flow_interp.argtypes = [i32, vp, C.POINTER(P.FlowDesc), i32, vp, vp, vp, i64, vp]
+    lib.mvrl_flow_reconstruct.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.mvrl_fill_uniform_dev.argtypes = [vp, vp, i64, u64, u64, fp, fp, vp]
+    lib.mvrl_timing_begin.argtypes = [vp, vp]
+    lib.mvrl_timing_end.argtypes = [vp, vp, C.POINTER(fp), C.POINTER(i64)]
+    lib.mvrl_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.mvrl_dev_free.argtypes = [vp, vp]
+    lib.mvrl_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.mvrl_dev_download.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.mvrl_synchronize.argtypes = [vp]
+    if lib.mvrl_abi_version() != P.ABI_VERSION:
+        raise MvrlError("libmvrl.so ABI version does not match the Python package")
+    _lib = lib
+    return lib
+
+
+def check(rc, handle=None):
+    if rc == 0:
+        return
+    msg = load().mvrl_last_error(handle)
+    raise MvrlError(f"libmvrl {ERRORS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+
+def device_count():
+    return int(load().mvrl_device_count())
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def flow_desc(n_t, n_y, n_x, dt, dx, dy):
+    d = P.FlowDesc()
+    d.n_t, d.n_y, d.n_x, d.dt, d.dx, d.dy = int(n_t), int(n_y), int(n_x), float(dt), float(dx), float(dy)
+    return d
+
+
+class Handle:
+    """Owning wrapper of one mvrl_handle (one shard of environments on one GPU)."""
+
+    def __init__(self, cfg):
+        self.lib = load()
+        self.cfg = cfg
+        self.model = int(cfg.model)
+        self.n = int(cfg.n_envs)
+        self.act_dim, self.obs_dim, self.init_dim, self.state_words, self.aux_dim = P.MODEL_DIMS[self.model]
+        h = C.c_void_p()
+        check(self.lib.mvrl_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self._obs = np.zeros((self.n, self.obs_dim), np.float32)
+        self._rew = np.zeros(self.n, np.float32)
+        self._done = np.zeros(self.n, np.uint8)
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mvrl_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def variant(self):
+        return self.lib.mvrl_variant(self.h).decode()
+
+    # -- flow -------------------------------------------------------------------------------------
+    def set_flow(self, table_uv, dt, dx, dy):
+        t = _f32(table_uv)
+        if t.ndim != 4 or t.shape[3] != 2:
+            raise ValueError("flow table must be [n_t, n_y, n_x, 2]")
+        d = flow_desc(t.shape[0], t.shape[1], t.shape[2], dt, dx, dy)
+        check(self.lib.mvrl_set_flow(self.h, t.ctypes.data, C.byref(d)), self.h)
+
+    def set_flow_dev(self, ptr, n_t, n_y, n_x, dt, dx, dy):
+        d = flow_desc(n_t, n_y, n_x, dt, dx, dy)
+        check(self.lib.mvrl_set_flow_dev(self.h, ptr, C.byref(d)), self.h)
+
+    # -- host-buffer API --------------------------------------------------------------------------
+    def reset(self, mask=None, init=None, obs_out=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.n)
+        ini = None if init is None else _f32(init, (self.n, self.init_dim))
+        obs = self._obs if obs_out is None else obs_out
+        check(self.lib.mvrl_reset(self.h, None if m is None else m.ctypes.data, None if ini is None else ini.ctypes.data,
+                                  obs.ctypes.data), self.h)
+        return obs
+
+    def step(self, actions):
+        a = None if actions is None else _f32(actions, (self.n, self.act_dim))
+        check(self.lib.mvrl_step(self.h, None if a is None else a.ctypes.data, self._obs.ctypes.data,
+                                 self._rew.ctypes.data, self._done.ctypes.data), self.h)
+        return self._obs, self._rew, self._done
+
+    def step_async(self, actions):
+        a = None if actions is None else _f32(actions, (self.n, self.act_dim))
+        check(self.lib.mvrl_step_async(self.h, None if a is None else a.ctypes.data), self.h)
+
+    def step_wait(self):
+        check(self.lib.mvrl_step_wait(self.h, self._obs.ctypes.data, self._rew.ctypes.data, self._done.ctypes.data),
+              self.h)
+        return self._obs, self._rew, self._done
+
+    def terminal_obs(self):
+        out = np.zeros((self.n, self.obs_dim), np.float32)
+        check(self.lib.mvrl_get_terminal_obs(self.h, out.ctypes.data), self.h)
+        return out
+
+    def get_state(self):
+        buf = np.zeros((self.state_words, self.n), np.float32)
+        check(self.lib.mvrl_get_state(self.h, buf.ctypes.data, buf.size), self.h)
+        return buf
+
+    def set_state(self, buf):
+        b = _f32(buf, (self.state_words, self.n))
+        check(self.lib.mvrl_set_state(self.h, b.ctypes.data, b.size), self.h)
+
+    def enable_aux(self, on=True):
+        check(self.lib.mvrl_enable_aux(self.h, 1 if on else 0), self.h)
+
+    def get_aux(self):
+        out = np.zeros((self.n, self.aux_dim), np.float32)
+        check(self.lib.mvrl_get_aux(self.h, out.ctypes.data), self.h)
+        return out
+
+    # -- device-pointer API (ints = raw device addresses, e.g. torch.Tensor.data_ptr()) -------------
+    def step_dev(self, actions_ptr, obs_ptr, reward_ptr, done_ptr, stream=None):
+        check(self.lib.mvrl_step_dev(self.h, actions_ptr, obs_ptr, reward_ptr, done_ptr, stream), self.h)
+
+    def reset_dev(self, mask_ptr, init_ptr, obs_ptr, stream=None):
+        check(self.lib.mvrl_reset_dev(self.h, mask_ptr, init_ptr, obs_ptr, stream), self.h)
+
+    def terminal_obs_dev(self, obs_ptr, stream=None):
+        check(self.lib.mvrl_get_terminal_obs_dev(self.h, obs_ptr, stream), self.h)
+
+    def fill_uniform_dev(self, ptr, n, seed, counter, lo=-1.0, hi=1.0, stream=None):
+        check(self.lib.mvrl_fill_uniform_dev(self.h, ptr, n, seed, counter, lo, hi, stream), self.h)
+
+    def timing_begin(self, stream=None):
+        check(self.lib.mvrl_timing_begin(self.h, stream), self.h)
+
+    def timing_end(self, stream=None):
+        ms, nl = C.c_float(), C.c_int64()
+        check(self.lib.mvrl_timing_end(self.h, stream, C.byref(ms), C.byref(nl)), self.h)
+        return ms.value, nl.value
+
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.lib.mvrl_dev_alloc(self.h, nbytes, C.byref(p)), self.h)
+        return p.value
+
+    def dev_free(self, ptr):
+        check(self.lib.mvrl_dev_free(self.h, ptr), self.h)
+
+    def dev_upload(self, ptr, arr):
+        a = np.ascontiguousarray(arr)
+        check(self.lib.mvrl_dev_upload(self.h, ptr, a.ctypes.data, a.nbytes), self.h)
+
+    def dev_download(self, ptr, arr):
+        assert arr.flags["C_CONTIGUOUS"]
+        check(self.lib.mvrl_dev_download(self.h, arr.ctypes.data, ptr, arr.nbytes), self.h)
+        return arr
+
+    def synchronize(self):
+        check(self.lib.mvrl_synchronize(self.h), self.h)
+
+
+def flow_interp(table, dt, dx, dy, t, x, y, device=0):
+    """ReconstructedFlow.interp on the GPU for arrays of query points (tag/flowGenerator.py:97-136)."""
+    lib = load()
+    tab = _f32(table)
+    if tab.ndim != 4 or not (1 <= tab.shape[3] <= 4):
+        raise ValueError("table must be [n_t, n_y, n_x, n_comp<=4]")
+    t, x, y = _f32(np.ravel(t)), _f32(np.ravel(x)), _f32(np.ravel(y))
+    out = np.zeros((len(t), tab.shape[3]), np.float32)
+    d = flow_desc(tab.shape[0], tab.shape[1], tab.shape[2], dt, dx, dy)
+    check(lib.mvrl_flow_interp(device, tab.ctypes.data, C.byref(d), tab.shape[3], t.ctypes.data, x.ctypes.data,
+                               y.ctypes.data, len(t), out.ctypes.data))
+    return out
+
+
+def flow_reconstruct(modes, coeffs, ltm, scale_mul, scale_add, device=0):
+    """flowData[t,j,i,c] = mul[c] * (Re(modes[j,i,c,:] @ coeffs[:,t]) + ltm[j,i,c]) + add[c] on the GPU
+    (tag/flowGenerator.py:19-23 fused with the affine map of scale(), :76-92)."""
+    lib = load()
+    ny, nx, nc, K = modes.shape
+    assert nc == 3 and coeffs.shape[0] == K
+    nT = coeffs.shape[1]
+    m2 = modes.reshape(ny * nx * 3, K)
+    mre, mim = _f32(m2.real), _f32(m2.imag)
+    cre, cim = _f32(coeffs.real), _f32(coeffs.imag)
+    l = _f32(ltm.reshape(-1))
+    mul, add = _f32(scale_mul, (3,)), _f32(scale_add, (3,))
+    out = np.zeros((nT, ny, nx, 3), np.float32)
+    check(lib.mvrl_flow_reconstruct(device, mre.ctypes.data, mim.ctypes.data, cre.ctypes.data, cim.ctypes.data,
+                                    l.ctypes.data, ny * nx * 3, K, nT, mul.ctypes.data, add.ctypes.data,
+                                    out.ctypes.data))
+    return out

@@ -1,0 +1,67 @@
+"""Build libmvrl.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+    python -m marinevehiclereinforcementlearning_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so lands next to this file so that it travels with the tree.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmvrl.so")
+SOURCES = ["mvrl_abi.hip", "mvrl_rov6.hip", "mvrl_rov3.hip", "mvrl_auv.hip", "mvrl_flow.hip"]
+HEADERS = ["mvrl_device.hpp", "mvrl_kernels.hpp", "mvrl_baked.inc"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", f"--offload-arch={ARCH}", "-I", CSRC, "-Wall",
+         "-Wno-unused-function"]
+
+
+def _gen_baked():
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import gen_baked
+    return gen_baked.main()
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_lib(force=False, verbose=False):
+    _gen_baked()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(REPO, "include", "mvrl.h")]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

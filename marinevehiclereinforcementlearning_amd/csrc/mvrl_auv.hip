@@ -1,0 +1,223 @@
+// mvrl_auv.hip - simplified 3-DoF AUV environment (explicit Euler + turbulence current + shaped reward).
+//
+// Replaces AuvEnv.step / reset / dataToState (tag_00_Dec2023_simpleControlTurbulence/verySimpleAuv.py:147-410)
+// including the flow lookup (flowGenerator.py:97-136) in one fused kernel per env step.  This one IS
+// bandwidth-shaped: ~150 flop against ~390 B per env step (53 state words, most of them the 10-deep action
+// ring the reward's smoothness term needs), so the layout work - SoA planes, one coalesced read + one
+// coalesced write per word - is what matters here.
+#include "mvrl_kernels.hpp"
+
+namespace mvrl {
+
+enum {
+    AV_X = 0, AV_Y = 1, AV_PSI = 2, AV_VX = 3, AV_VY = 4, AV_R = 5, AV_TGT = 6, AV_HERR_O = 7, AV_PERR_O = 8,
+    AV_MULT = 10,   // m I Xuu Yvv Nrr Xu Yv Nr Xact Yact Nact  (verySimpleAuv.py:222-229)
+    AV_TOFF = 21, AV_HIST = 22, AV_ISTEP = 52, AV_WORDS = 53
+};
+
+// dataToState "V3" (verySimpleAuv.py:201-212); positionTarget = 0 (:241)
+__device__ __forceinline__ void observe_auv(float x, float y, float psi, float vx, float vy, float r, float tgt,
+                                            float herr_o, float perr_ox, float perr_oy, float* o) {
+    float perr0 = 0.f - x, perr1 = 0.f - y;
+    float herr = angle_error(tgt, psi);
+    o[0] = clampf(perr0, -1.f, 1.f);
+    o[1] = clampf(perr1, -1.f, 1.f);
+    o[2] = clampf(herr * (1.0f / 0.78539816339744830962f), -1.f, 1.f);
+    o[3] = clampf(herr - herr_o, -1.f, 1.f);
+    o[4] = clampf(perr0 - perr_ox, -1.f, 1.f);
+    o[5] = clampf(perr1 - perr_oy, -1.f, 1.f);
+    o[6] = clampf(vx, -1.f, 1.f);
+    o[7] = clampf(vy, -1.f, 1.f);
+    o[8] = clampf(r, -1.f, 1.f);
+    o[9] = 0.f;
+    o[10] = 0.f;
+}
+
+// reset draws (verySimpleAuv.py:222-245), order: 8 coefficient multipliers, 3 actuation multipliers,
+// position (2), heading, headingTarget, flow time offset
+__device__ __forceinline__ void random_init_auv(const AuvDev& p, uint64_t seed, int64_t gid, uint32_t epoch, float t_quarter,
+                                                float* v /*16: x y psi tgt toff mult[11]*/) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t g0 = (uint32_t)gid, g1 = (uint32_t)((uint64_t)gid >> 32);
+    float u[16];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        Philox4 r = philox4x32_10(g0, g1, epoch, (uint32_t)b, k0, k1);
+#pragma unroll
+        for (int q = 0; q < 4; q++) u[4 * b + q] = u01(r.v[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[5 + q] = 1.f + 0.5f * p.noise_coeffs - u[q] * p.noise_coeffs;
+#pragma unroll
+    for (int q = 0; q < 3; q++) v[13 + q] = 1.f + 0.5f * p.noise_act - u[8 + q] * p.noise_act;
+    v[0] = (u[11] - 0.5f) * 0.5f * (p.x_max - p.x_min);
+    v[1] = (u[12] - 0.5f) * 0.5f * (p.y_max - p.y_min);
+    v[2] = u[13] * MVRL_TWO_PI_HI;
+    v[3] = u[14] * MVRL_TWO_PI_HI;
+    v[4] = u[15] * t_quarter;
+}
+
+template <bool FLOW>
+__global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, const StepIO io, const FlowDev fl) {
+    const uint32_t i = blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= (uint32_t)io.n) return;
+    const uint32_t n32 = (uint32_t)io.n;
+    char* const stb = reinterpret_cast<char*>(io.state);
+#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) << 2)))
+    float x = ST(AV_X), y = ST(AV_Y), psi = ST(AV_PSI), vx = ST(AV_VX), vy = ST(AV_VY), r = ST(AV_R);
+    const float tgt = ST(AV_TGT);
+    float herr_o = ST(AV_HERR_O), perr_ox = ST(AV_PERR_O), perr_oy = ST(AV_PERR_O + 1);
+    float mu[11];
+#pragma unroll
+    for (int q = 0; q < 11; q++) mu[q] = ST(AV_MULT + q);
+    float hist[30];
+#pragma unroll
+    for (int q = 0; q < 30; q++) hist[q] = ST(AV_HIST + q);
+    int istep = __float_as_int(ST(AV_ISTEP));
+    const float* ap = io.actions + (size_t)i * 3;
+    const float a0 = ap[0], a1 = ap[1], a2 = ap[2];
+
+    istep += 1;                                  // verySimpleAuv.py:266
+    const float time = (float)istep * io.dt;     // :267
+    bool done = istep >= io.max_steps;           // :270-272
+    const int slot = (istep - 1) % 10;           // recentActions.appendleft (:275) as a ring
+    const int nh = istep < 10 ? istep : 10;
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        hist[3 * j + 0] = (j == slot) ? a0 : hist[3 * j + 0];
+        hist[3 * j + 1] = (j == slot) ? a1 : hist[3 * j + 1];
+        hist[3 * j + 2] = (j == slot) ? a2 : hist[3 * j + 2];
+    }
+    const float Fset0 = a0 * p.max_force * mu[8], Fset1 = a1 * p.max_force * mu[9];   // :278
+    const float Nset = a2 * p.max_moment * mu[10];                                      // :279
+    float sn, c;
+    sincos_f32(psi, sn, c);
+    float2 cur = make_float2(0.f, 0.f);
+    if (FLOW) cur = flow_interp_uv(fl, time + ST(AV_TOFF), x, y);                       // :291
+    const float dvx = vx - cur.x, dvy = vy - cur.y;
+    const float vr0 = c * dvx + sn * dvy, vr1 = -sn * dvx + c * dvy;                    // :298 (pinv(J) = J^T)
+    const float Fh0 = (p.xu * mu[5] + p.xuu * mu[2] * fabsf(vr0)) * vr0;                // :303-307
+    const float Fh1 = (p.yv * mu[6] + p.yvv * mu[3] * fabsf(vr1)) * vr1;
+    const float Fh2 = (p.nr * mu[7] + p.nrr * mu[4] * fabsf(r)) * r;
+    const float Fg0 = c * Fh0 - sn * Fh1, Fg1 = sn * Fh0 + c * Fh1;                     // :310
+    const float acc0 = (Fg0 + Fset0) / (p.m * mu[0]);                                   // :314-318
+    const float acc1 = (Fg1 + Fset1) / (p.m * mu[0]);
+    const float acc2 = (Fh2 + Nset) / (p.izz * mu[1]);
+    const float h = io.dt;                                                              // :321-326 explicit Euler
+    x = fmaf(vx, h, x); y = fmaf(vy, h, y);
+    psi = mod_two_pi(fmaf(r, h, psi));
+    vx = fmaf(acc0, h, vx); vy = fmaf(acc1, h, vy); r = fmaf(acc2, h, r);
+
+    float o[11];
+    observe_auv(x, y, psi, vx, vy, r, tgt, herr_o, perr_ox, perr_oy, o);               // :329
+    float bonus = 0.f;                                                                  // :335-342
+    if (x < p.x_min || x > p.x_max) { if (p.stop_on_bounds) done = true; bonus += -100.f; }
+    if (y < p.y_min || y > p.y_max) { if (p.stop_on_bounds) done = true; bonus += -100.f; }
+    const float perr0 = 0.f - x, perr1 = 0.f - y;
+    const float herr = angle_error(tgt, psi);
+    herr_o = herr; perr_ox = perr0; perr_oy = perr1;                                    // :349-350
+    float rms = 0.f;                                                                    // :353-355
+    const float inv_nh = 1.0f / (float)nh;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float mean = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; j++) mean += (j < nh) ? hist[3 * j + k] : 0.f;
+        mean *= inv_nh;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; j++) { float d = hist[3 * j + k] - mean; ss += (j < nh) ? d * d : 0.f; }
+        rms += sqrtf(ss * inv_nh);
+    }
+    rms *= (1.0f / 3.0f);
+    const float PI = 3.14159265358979323846f;
+    const float hdeg = herr * (180.0f / PI);
+    const float t0 = expf(-5.f * sqrtf(perr0 * perr0 + perr1 * perr1));                 // :357-381
+    const float t1 = (fabsf(herr) < 0.5f * PI) ? expf(-0.1f * fabsf(hdeg)) : -expf(-0.1f * (180.f - fabsf(hdeg)));
+    const float t2 = expf(-0.6f * rms);
+    const float t3 = -0.1f * (a0 * a0 + a1 * a1 + a2 * a2) * (1.0f / 3.0f);
+    io.reward[i] = (((t0 + t1) + t2) + t3) + bonus;
+    io.done[i] = done ? 1 : 0;
+    if (io.aux) {  // timeHistory: Fx Fy N u_current v_current rmsAc r0..r4 (:389-403)
+        float* ax = io.aux + (size_t)i * 11;
+        ax[0] = Fg0; ax[1] = Fg1; ax[2] = Fh2; ax[3] = cur.x; ax[4] = cur.y; ax[5] = rms;
+        ax[6] = t0; ax[7] = t1; ax[8] = t2; ax[9] = t3; ax[10] = bonus;
+    }
+    if (done && io.auto_reset) {
+        if (io.term_obs) {
+#pragma unroll
+            for (int q = 0; q < 11; q++) io.term_obs[(size_t)i * 11 + q] = o[q];
+        }
+        float v[16];
+        random_init_auv(p, io.seed, io.env_offset + (int64_t)i, io.epoch, fl.t_quarter, v);
+        x = v[0]; y = v[1]; psi = v[2]; vx = 0.f; vy = 0.f; r = 0.f;
+        ST(AV_TGT) = v[3];
+        ST(AV_TOFF) = v[4];
+#pragma unroll
+        for (int q = 0; q < 11; q++) ST(AV_MULT + q) = v[5 + q];
+        perr_ox = 0.f - x; perr_oy = 0.f - y; herr_o = angle_error(v[3], psi);         // herr_o = None -> first call (:160-162)
+        istep = 0;
+        observe_auv(x, y, psi, vx, vy, r, v[3], herr_o, perr_ox, perr_oy, o);
+    } else {
+        // only the ring slot that changed is written back
+#pragma unroll
+        for (int k = 0; k < 3; k++) ST(AV_HIST + 3 * slot + k) = (k == 0) ? a0 : ((k == 1) ? a1 : a2);
+    }
+#pragma unroll
+    for (int q = 0; q < 11; q++) io.obs[(size_t)i * 11 + q] = o[q];
+    ST(AV_X) = x; ST(AV_Y) = y; ST(AV_PSI) = psi; ST(AV_VX) = vx; ST(AV_VY) = vy; ST(AV_R) = r;
+    ST(AV_HERR_O) = herr_o; ST(AV_PERR_O) = perr_ox; ST(AV_PERR_O + 1) = perr_oy;
+    ST(AV_ISTEP) = __int_as_float(istep);
+#undef ST
+}
+
+__global__ __launch_bounds__(MVRL_BLOCK) void auv_reset_kernel(const AuvDev p, float* state, int64_t n, const uint8_t* mask,
+                                                               const float* init, float* obs, uint64_t seed,
+                                                               int64_t env_offset, uint32_t epoch, float t_quarter) {
+    const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (mask && !mask[i]) return;
+    float* st = state + i;
+    float v[16];
+    if (init) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = init[i * 16 + q];
+    } else {
+        random_init_auv(p, seed, env_offset + i, epoch, t_quarter, v);
+    }
+    const float x = v[0], y = v[1], psi = v[2], tgt = v[3];
+    st[AV_X * n] = x; st[AV_Y * n] = y; st[AV_PSI * n] = psi;
+    st[AV_VX * n] = 0.f; st[AV_VY * n] = 0.f; st[AV_R * n] = 0.f;
+    st[AV_TGT * n] = tgt;
+    const float herr_o = angle_error(tgt, psi), perr_ox = 0.f - x, perr_oy = 0.f - y;
+    st[AV_HERR_O * n] = herr_o; st[AV_PERR_O * n] = perr_ox; st[(AV_PERR_O + 1) * n] = perr_oy;
+#pragma unroll
+    for (int q = 0; q < 11; q++) st[(AV_MULT + q) * n] = v[5 + q];
+    st[AV_TOFF * n] = v[4];
+#pragma unroll
+    for (int q = 0; q < 30; q++) st[(AV_HIST + q) * n] = 0.f;
+    st[AV_ISTEP * n] = __int_as_float(0);
+    if (obs) {
+        float o[11];
+        observe_auv(x, y, psi, 0.f, 0.f, 0.f, tgt, herr_o, perr_ox, perr_oy, o);
+#pragma unroll
+        for (int q = 0; q < 11; q++) obs[i * 11 + q] = o[q];
+    }
+}
+
+hipError_t launch_auv_step(const AuvDev& p, const StepIO& io, const FlowDev& fl, bool flow, hipStream_t stream) {
+    dim3 grid((unsigned)((io.n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    if (flow) hipLaunchKernelGGL((auv_step_kernel<true>), grid, block, 0, stream, p, io, fl);
+    else hipLaunchKernelGGL((auv_step_kernel<false>), grid, block, 0, stream, p, io, fl);
+    return hipGetLastError();
+}
+
+hipError_t launch_auv_reset(const AuvDev& p, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
+                            uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    hipLaunchKernelGGL(auv_reset_kernel, grid, block, 0, stream, p, state, n, mask, init, obs, seed, env_offset, epoch,
+                       t_quarter);
+    return hipGetLastError();
+}
+
+}  // namespace mvrl

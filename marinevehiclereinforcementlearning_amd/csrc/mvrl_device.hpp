@@ -1,0 +1,214 @@
+// mvrl_device.hpp - device-side building blocks shared by the environment kernels (gfx950 / CDNA4).
+//
+// One wavefront lane = one environment instance.  All per-env state lives in HBM as SoA planes
+// (plane k of env i at base[k * n + i]) so that every state load/store of a wave is one fully coalesced
+// 256-B transaction; model constants are wave-uniform kernel arguments (scalar loads -> SGPRs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#define MVRL_BLOCK 256
+
+namespace mvrl {
+
+// ---- fp32 math helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float fsign(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+// 2*pi split for Cody-Waite style reduction: TWO_PI_HI + TWO_PI_LO == 2*pi to ~1e-15
+#define MVRL_TWO_PI_HI 6.2831855f
+#define MVRL_TWO_PI_LO (-1.7484555e-7f)
+#define MVRL_INV_TWO_PI 0.15915494f
+
+// Python float modulo x % (2*pi) -> [0, 2*pi)   (resources.py:92-93, 6DoF.py:560)
+__device__ __forceinline__ float mod_two_pi(float x) {
+    float q = floorf(x * MVRL_INV_TWO_PI);
+    float r = fmaf(-q, MVRL_TWO_PI_HI, x);
+    r = fmaf(-q, MVRL_TWO_PI_LO, r);
+    // q may be off by one when x sits next to a multiple of 2*pi
+    r = (r < 0.f) ? r + MVRL_TWO_PI_HI : r;
+    r = (r >= MVRL_TWO_PI_HI) ? r - MVRL_TWO_PI_HI : r;
+    return r;
+}
+
+// resources.angleError (resources.py:75-95): signed difference in [-pi, pi)
+__device__ __forceinline__ float angle_error(float psi_d, float psi) {
+    float d = psi_d - psi;
+    float a = mod_two_pi(d);
+    float b = mod_two_pi(-d);
+    return (a < b) ? a : -b;
+}
+
+// sin & cos with ~1 ulp accuracy for |x| up to a few thousand radians, branch-free (Cody-Waite reduction by
+// pi/2 in three exact-product pieces + Cephes-style minimax polynomials on [-pi/4, pi/4]).
+__device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
+    float q = rintf(x * 0.63661977f);
+    float r = fmaf(-q, 1.5703125f, x);
+    r = fmaf(-q, 4.837512969970703125e-4f, r);
+    r = fmaf(-q, 7.54978995489188216e-8f, r);
+    float r2 = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    float sn = fmaf(ps * r2, r, r);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+    float cn = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    int n = (int)q;
+    float s1 = (n & 1) ? cn : sn;
+    float c1 = (n & 1) ? sn : cn;
+    s = (n & 2) ? -s1 : s1;
+    c = ((n + 1) & 2) ? -c1 : c1;
+}
+
+// ---- Philox4x32-10 counter-based RNG (Salmon et al. 2011) -----------------------------------------
+// Streams are keyed by (seed) and counted by (global env id, epoch, slot) so results do not depend on how
+// the batch is sharded over GPUs.
+struct Philox4 {
+    uint32_t v[4];
+};
+__device__ __host__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+// uniform in [0, 1) with 24 random bits (exactly representable in fp32)
+__device__ __host__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// ---- turbulence table -----------------------------------------------------------------------------
+struct FlowDev {
+    const float2* table;  // [n_t][n_y][n_x] of (u, v)
+    int n_t, n_y, n_x;
+    float inv_dt, inv_dx, inv_dy;
+    float t_quarter;      // flow.time[n_t // 4]  (verySimpleAuv.py:245)
+};
+
+// ReconstructedFlow.interp restricted to (u, v) (tag/flowGenerator.py:97-136): cell index clamped, weights NOT
+// clamped (linear extrapolation outside the table), origin ignored - all as the reference.
+__device__ __forceinline__ float2 flow_interp_uv(const FlowDev& f, float time, float x, float y) {
+    float tt = time * f.inv_dt, xx = x * f.inv_dx, yy = y * f.inv_dy;
+    int kk = min(f.n_t - 2, max(0, (int)floorf(tt)));
+    int ii = min(f.n_x - 2, max(0, (int)floorf(xx)));
+    int jj = min(f.n_y - 2, max(0, (int)floorf(yy)));
+    float ft = tt - (float)kk, fx = xx - (float)ii, fy = yy - (float)jj;
+    float wt0 = 1.f - ft, wx0 = 1.f - fx, wy0 = 1.f - fy;
+    const float2* p0 = f.table + ((size_t)kk * f.n_y + jj) * f.n_x + ii;
+    const float2* p1 = p0 + (size_t)f.n_y * f.n_x;
+    // 8 corner gathers of 8 B each (entries are only 8-byte aligned, so no 16-byte loads); the x-neighbours are
+    // adjacent in memory and share a cache line almost always.
+    float2 c000 = p0[0], c001 = p0[1], c010 = p0[f.n_x], c011 = p0[f.n_x + 1];
+    float2 c100 = p1[0], c101 = p1[1], c110 = p1[f.n_x], c111 = p1[f.n_x + 1];
+    float u0 = wy0 * (c000.x * wx0 + c001.x * fx) + fy * (c010.x * wx0 + c011.x * fx);
+    float v0 = wy0 * (c000.y * wx0 + c001.y * fx) + fy * (c010.y * wx0 + c011.y * fx);
+    float u1 = wy0 * (c100.x * wx0 + c101.x * fx) + fy * (c110.x * wx0 + c111.x * fx);
+    float v1 = wy0 * (c100.y * wx0 + c101.y * fx) + fy * (c110.y * wx0 + c111.y * fx);
+    return make_float2(u0 * wt0 + u1 * ft, v0 * wt0 + v1 * ft);
+}
+
+// ---- device mirrors of the model constants (fp32) -------------------------------------------------
+struct Rov6Dev {
+    float m, wb;            // mass, W - B
+    float cg[3];
+    float I[9];
+    float gw[3];            // (xg*W - xb*B), (yg*W - yb*B), (zg*W - zb*B)
+    float added[6];
+    float minv[36];
+    float dlin[36];
+    float dquad[36];
+    float A[48];
+    float Ainv[48];
+    // sign-symmetric thruster layout (valid when the host selected the SYM kernel):
+    //   sym_a    = |A[0,0]| |A[1,0]| |A[2,4]| |A[3,0]| |A[3,4]| |A[4,0]| |A[4,4]| |A[5,0]|
+    //   sym_ainv = |Ainv[0,0]| |Ainv[0,1]| |Ainv[0,5]| |Ainv[4,0]| |Ainv[4,1]| |Ainv[4,2]| |Ainv[4,3]| |Ainv[4,4]|
+    float sym_a[8];
+    float sym_ainv[8];
+    float thrust_k, inv_thrust_k, rpm_max, rpm_dead, f_max, f_dead;
+    float kp[6], ki[6], kd[6], windup[6], umax[6];
+    float act_scale[6];
+    float inv_obs_pos, inv_obs_ang;
+};
+
+struct Rov3Dev {
+    float m, cgx, cgy;
+    float xud, yvd;
+    float minv[9], dlin[9], dquad[9];
+    float Ainv[12];
+    float thrust_k, inv_thrust_k, rpm_max, rpm_dead, f_max, f_dead;
+    float cos_a, sin_a, yaw_arm, inv_jet_area_k, jet_c1, jet_k1, jet_c2, jet_k2, jet_drag_k;
+    float kp[3], ki[3], kd[3], windup[3], umax[3];
+    float act_scale[3];
+    float inv_obs_pos, inv_obs_ang;
+};
+
+struct AuvDev {
+    float m, izz, xuu, yvv, nrr, xu, yv, nr, max_force, max_moment;
+    float x_min, x_max, y_min, y_max;
+    float noise_coeffs, noise_act;
+    int stop_on_bounds;
+};
+
+// Model constants are read through a CONSTANT-address-space pointer so that they come in through the scalar
+// cache (s_load_dwordxN -> SGPR operands, no VALU or VGPR cost).  A 6-DoF RHS touches ~140 distinct constants,
+// more than the ~100 SGPRs a wave owns; left alone, LLVM hoists all of them out of the RK4 loop and spills the
+// excess into VGPR lanes (v_writelane/v_readlane = one VALU slot per use).  `launder` hides the pointer's
+// provenance at the start of each phase (PID / allocation / dynamics), so each phase re-issues a few wide
+// scalar loads (scalar-cache hits) instead.
+typedef const __attribute__((address_space(4))) Rov6Dev* CP6;
+typedef const __attribute__((address_space(4))) Rov3Dev* CP3;
+typedef const __attribute__((address_space(4))) AuvDev* CPA;
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* as_const(const T* p) {
+    return (const __attribute__((address_space(4))) T*)(uintptr_t)p;
+}
+template <class PT>
+__device__ __forceinline__ PT launder(PT p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+}  // namespace mvrl
+#include "mvrl_baked.inc"
+namespace mvrl {
+// Baked flavour: `p->field` resolves to a static constexpr member, i.e. an instruction literal; nothing to launder.
+__device__ __forceinline__ const Rov6Baked* launder(const Rov6Baked* p) { return p; }
+__device__ __forceinline__ const Rov3Baked* launder(const Rov3Baked* p) { return p; }
+template <class PP, class T>
+__device__ __forceinline__ PP param_ptr(const T* pg) {
+    if constexpr (std::is_same<PP, const Rov6Baked*>::value || std::is_same<PP, const Rov3Baked*>::value) {
+        return nullptr;  // never dereferenced: every member is static
+    } else {
+        return (PP)(uintptr_t)pg;
+    }
+}
+
+// ---- common launch arguments ----------------------------------------------------------------------
+struct StepIO {
+    float* state;           // SoA planes [words][n]
+    const float* actions;   // [n][act_dim]
+    float* obs;             // [n][obs_dim]
+    float* reward;          // [n]
+    uint8_t* done;          // [n]
+    float* term_obs;        // [n][obs_dim] or nullptr
+    float* aux;             // [n][aux_dim] or nullptr
+    int64_t n;
+    int64_t env_offset;
+    uint64_t seed;
+    uint32_t epoch;         // RNG epoch of this call
+    int n_sub;
+    int max_steps;
+    int fixed_sp;
+    int auto_reset;
+    float dt;
+};
+
+}  // namespace mvrl

@@ -1,0 +1,296 @@
+// mvrl_rov3.hip - BlueROV2 Heavy 3-DoF environment step / reset kernels for gfx950.
+//
+// Replaces BlueROV2Heavy3DoFEnv.step/reset/dataToState and BlueROV2Heavy3DoF.derivs with its inlined PID,
+// 4-thruster allocation and jet-drag augment (dynamicsModel_BlueROV2_Heavy_3DoF.py:114-296, :397-514).
+// Same structure as the 6-DoF kernel: one lane per env, SoA state read/written once per step.
+#include "mvrl_kernels.hpp"
+
+namespace mvrl {
+
+struct Pid3 {
+    float eold[3];
+    float eint[3];
+};
+
+// PID + body-frame resolution + allocation + saturation (3DoF.py:141-180) -> limited thruster forces F[4]
+template <bool HAS_DT, class PP>
+__device__ __forceinline__ void control3(PP p, const float* y, const float* sp, Pid3& s, float dtp, float inv_den,
+                                         float c, float sn, float* F, float* gcf, float* cv_raw, bool keep) {
+    p = launder(p);
+    float e[3] = {sp[0] - y[0], sp[1] - y[1], angle_error(sp[2], y[2])};
+    float u[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float dedt = (e[i] - s.eold[i]) * inv_den;
+        if (HAS_DT) s.eint[i] = fmaf(0.5f * (s.eold[i] + e[i]), dtp, s.eint[i]);
+        s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
+        float v = fmaf(p->ki[i], s.eint[i], fmaf(p->kd[i], dedt, p->kp[i] * e[i]));
+        u[i] = clampf(v, -p->umax[i], p->umax[i]);
+        s.eold[i] = e[i];
+    }
+    float Xd = u[0] * c + u[1] * sn, Yd = -u[0] * sn + u[1] * c, Nd = u[2];
+    if (keep) { gcf[0] = Xd; gcf[1] = Yd; gcf[2] = Nd; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float cv = fmaf(p->Ainv[3 * i + 2], Nd, fmaf(p->Ainv[3 * i + 1], Yd, p->Ainv[3 * i] * Xd));
+        float f = clampf(cv, -p->f_max, p->f_max);   // rpm clamp +-3500 and dead-band 300 in force space (3DoF.py:171-180)
+        F[i] = (fabsf(f) < p->f_dead) ? 0.f : f;
+        if (keep) cv_raw[i] = cv;
+    }
+}
+
+// forces + solve + kinematics (3DoF.py:182-296) for given limited thruster forces
+template <bool FLOW, class PP>
+__device__ __forceinline__ void dynamics3(PP p, const float* y, float c, float sn, const float* F, float2 cur,
+                                          float* dy) {
+    p = launder(p);
+    const float u = y[3], v = y[4], r = y[5];
+    float uRel = u, vRel = v;
+    if (FLOW) {  // pinv(J) = J^T (3DoF.py:186-188)
+        uRel -= c * cur.x + sn * cur.y;
+        vRel -= -sn * cur.x + c * cur.y;
+    }
+    const float vr[3] = {uRel, vRel, r};
+    const float av[3] = {fabsf(uRel), fabsf(vRel), fabsf(r)};
+    // thruster jet-drag augment (3DoF.py:114-126)
+    float au = fabsf(u);
+    float drag = -p->jet_drag_k * au * u;
+    float Xsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float uJet = sqrtf(fabsf(F[i]) * p->inv_jet_area_k);
+        float q = au / fmaxf(1e-5f, uJet);
+        float dCd = p->jet_c1 * expf(-p->jet_k1 * q) + p->jet_c2 * expf(-p->jet_k2 * q);
+        Xsum += dCd * drag;
+    }
+    float H[3];
+    H[0] = Xsum + (F[0] + F[1] - F[2] - F[3]) * p->cos_a;  // 3DoF.py:255-263
+    H[1] = (F[0] - F[1] + F[2] - F[3]) * p->sin_a;
+    H[2] = p->yaw_arm * (F[0] + F[1] + F[2] + F[3]);
+    const float m = p->m;
+    float ka = m * (p->cgx * r + v), kb = m * (p->cgy * r - u);
+    float c1[3] = {-ka * r, -kb * r, ka * u + kb * v};                      // Crb . vel   (3DoF.py:210-214)
+    float ca[3] = {p->yvd * vRel * r, -p->xud * uRel * r, -p->yvd * vRel * uRel + p->xud * uRel * vRel};  // Ca . velRel
+    float R[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; j++) d = fmaf(fmaf(p->dquad[3 * i + j], av[j], p->dlin[3 * i + j]), vr[j], d);
+        R[i] = -c1[i] - (ca[i] + d) + H[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) dy[3 + i] = fmaf(p->minv[3 * i + 2], R[2], fmaf(p->minv[3 * i + 1], R[1], p->minv[3 * i] * R[0]));
+    dy[0] = c * u - sn * v;
+    dy[1] = sn * u + c * v;
+    dy[2] = r;
+}
+
+template <bool FLOW, bool HAS_DT, class PP>
+__device__ __forceinline__ void derivs3(PP p, const float* y, const float* sp, Pid3& pid, float dtp, float inv_den,
+                                        float2 cur, float* dy, float* gcf, float* cv_raw, bool keep) {
+    float sn, c;
+    sincos_f32(y[2], sn, c);
+    float F[4];
+    control3<HAS_DT>(p, y, sp, pid, dtp, inv_den, c, sn, F, gcf, cv_raw, keep);
+    dynamics3<FLOW>(p, y, c, sn, F, cur, dy);
+}
+
+template <class PP>
+__device__ __forceinline__ void observe3(PP p, const float* y, const float* path, const float* sp, float* o) {
+    o[0] = clampf((path[0] - y[0]) * p->inv_obs_pos, -1.f, 1.f);  // 3DoF.py:397-409
+    o[1] = clampf((path[1] - y[1]) * p->inv_obs_pos, -1.f, 1.f);
+    o[2] = clampf((path[2] - y[0]) * p->inv_obs_pos, -1.f, 1.f);
+    o[3] = clampf((path[3] - y[1]) * p->inv_obs_pos, -1.f, 1.f);
+    o[4] = clampf(angle_error(sp[2], y[2]) * p->inv_obs_ang, -1.f, 1.f);
+}
+
+// 3DoF.py:423-424: path = (rand(4).reshape(2,2) - 0.5) * 10, heading = rand() * 2 pi
+__device__ __forceinline__ void random_init3(uint64_t seed, int64_t gid, uint32_t epoch, float t_quarter, float* path,
+                                             float& heading, float& toffset) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t g0 = (uint32_t)gid, g1 = (uint32_t)((uint64_t)gid >> 32);
+    Philox4 r0 = philox4x32_10(g0, g1, epoch, 0u, k0, k1);
+    Philox4 r1 = philox4x32_10(g0, g1, epoch, 1u, k0, k1);
+#pragma unroll
+    for (int q = 0; q < 4; q++) path[q] = (u01(r0.v[q]) - 0.5f) * 10.f;
+    heading = u01(r1.v[0]) * MVRL_TWO_PI_HI;
+    toffset = u01(r1.v[1]) * t_quarter;
+}
+
+enum { R3_Y = 0, R3_EOLD = 6, R3_EINT = 9, R3_SP = 12, R3_PATH = 15, R3_TOFF = 19, R3_ISTEP = 20, R3_WORDS = 21 };
+
+template <class PP, bool ZOH, bool FLOW>
+__global__ __launch_bounds__(MVRL_BLOCK) void rov3_step_kernel(const Rov3Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
+    const PP p = param_ptr<PP>(pg);
+    const uint32_t i = blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= (uint32_t)io.n) return;
+    const uint32_t n32 = (uint32_t)io.n;  // see mvrl_rov6.hip: 32-bit byte offsets -> saddr addressing
+    char* const stb = reinterpret_cast<char*>(io.state);
+#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) << 2)))
+    float y[6], sp[3], path[4];
+    Pid3 pid;
+#pragma unroll
+    for (int k = 0; k < 6; k++) y[k] = ST(R3_Y + k);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pid.eold[k] = ST(R3_EOLD + k); pid.eint[k] = ST(R3_EINT + k); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) path[k] = ST(R3_PATH + k);
+    int istep = __float_as_int(ST(R3_ISTEP));
+    if (io.fixed_sp) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) sp[k] = ST(R3_SP + k);
+    } else {  // 3DoF.py:469-472
+        const float* a = io.actions + (size_t)i * 3;
+        sp[0] = fmaf(a[0], p->act_scale[0], y[0]);
+        sp[1] = fmaf(a[1], p->act_scale[1], y[1]);
+        sp[2] = fmaf(a[2], p->act_scale[2], y[2]);
+    }
+    const bool first = (istep == 0);
+    istep += 1;
+    float2 cur = make_float2(0.f, 0.f);
+    if (FLOW) cur = flow_interp_uv(fl, (float)istep * io.dt + ST(R3_TOFF), y[0], y[1]);
+    if (first) { pid.eold[0] = sp[0] - y[0]; pid.eold[1] = sp[1] - y[1]; pid.eold[2] = angle_error(sp[2], y[2]); }
+
+    const float h = io.dt / (float)io.n_sub, hh = 0.5f * h, h6 = h / 6.f, inv_hh = 1.0f / hh;
+    float gcf[3] = {0, 0, 0}, cvr[4] = {0, 0, 0, 0};
+    const bool want_aux = (io.aux != nullptr);
+    for (int ks = 0; ks < io.n_sub; ks++) {
+        float k[6], acc[6], yt[6];
+        const bool last = want_aux && (ks == io.n_sub - 1);
+        if (ZOH) {
+            float sn, c, F[4];
+            sincos_f32(y[2], sn, c);
+            if (first && ks == 0) control3<false>(p, y, sp, pid, 0.f, 1e9f, c, sn, F, gcf, cvr, true);
+            else control3<true>(p, y, sp, pid, h, 1.0f / h, c, sn, F, gcf, cvr, true);
+            dynamics3<FLOW>(p, y, c, sn, F, cur, k);
+#pragma unroll
+            for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
+            sincos_f32(yt[2], sn, c);
+            dynamics3<FLOW>(p, yt, c, sn, F, cur, k);
+#pragma unroll
+            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
+            sincos_f32(yt[2], sn, c);
+            dynamics3<FLOW>(p, yt, c, sn, F, cur, k);
+#pragma unroll
+            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
+            sincos_f32(yt[2], sn, c);
+            dynamics3<FLOW>(p, yt, c, sn, F, cur, k);
+        } else {
+            derivs3<FLOW, false>(p, y, sp, pid, 0.f, 1e9f, cur, k, gcf, cvr, false);
+#pragma unroll
+            for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
+            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, cur, k, gcf, cvr, false);
+#pragma unroll
+            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
+            derivs3<FLOW, false>(p, yt, sp, pid, 0.f, 1e9f, cur, k, gcf, cvr, false);
+#pragma unroll
+            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
+            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, cur, k, gcf, cvr, last);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) y[q] = fmaf(h6, acc[q] + k[q], y[q]);
+    }
+    y[2] = mod_two_pi(y[2]);  // 3DoF.py:480
+    float o[5];
+    observe3(p, y, path, sp, o);
+    const bool done = istep >= io.max_steps;
+    if (want_aux) {  // timeHistory F0..F2, u0..u3 (3DoF.py:498-507)
+        float* ax = io.aux + (size_t)i * 7;
+        ax[0] = gcf[0]; ax[1] = gcf[1]; ax[2] = gcf[2];
+#pragma unroll
+        for (int q = 0; q < 4; q++) ax[3 + q] = fsign(cvr[q]) * sqrtf(fabsf(cvr[q]) * p->inv_thrust_k) * 60.f;
+    }
+    io.reward[i] = 0.f;
+    io.done[i] = done ? 1 : 0;
+    if (done && io.auto_reset) {
+        if (io.term_obs) {
+#pragma unroll
+            for (int q = 0; q < 5; q++) io.term_obs[(size_t)i * 5 + q] = o[q];
+        }
+        if (!io.fixed_sp) {
+            float heading, toff;
+            random_init3(io.seed, io.env_offset + (int64_t)i, io.epoch, fl.t_quarter, path, heading, toff);
+#pragma unroll
+            for (int q = 0; q < 4; q++) ST(R3_PATH + q) = path[q];
+            ST(R3_TOFF) = toff;
+            sp[0] = path[0]; sp[1] = path[1]; sp[2] = heading;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) y[q] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; q++) { pid.eold[q] = 0.f; pid.eint[q] = 0.f; }
+        istep = 0;
+        observe3(p, y, path, sp, o);
+    }
+#pragma unroll
+    for (int q = 0; q < 5; q++) io.obs[(size_t)i * 5 + q] = o[q];
+#pragma unroll
+    for (int k = 0; k < 6; k++) ST(R3_Y + k) = y[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ST(R3_EOLD + k) = pid.eold[k]; ST(R3_EINT + k) = pid.eint[k]; }
+    if (!io.fixed_sp) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) ST(R3_SP + k) = sp[k];
+    }
+    ST(R3_ISTEP) = __int_as_float(istep);
+#undef ST
+}
+
+__global__ __launch_bounds__(MVRL_BLOCK) void rov3_reset_kernel(const Rov3Dev* __restrict__ pg, float* state, int64_t n, const uint8_t* mask,
+                                                                const float* init, float* obs, uint64_t seed,
+                                                                int64_t env_offset, uint32_t epoch, float t_quarter) {
+    const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (mask && !mask[i]) return;
+    const CP3 p = as_const(pg);
+    float* st = state + i;
+    float path[4], sp[3], y[6] = {0, 0, 0, 0, 0, 0}, toff = 0.f;
+    if (init) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) path[q] = init[i * 5 + q];
+        sp[2] = init[i * 5 + 4];
+    } else {
+        random_init3(seed, env_offset + i, epoch, t_quarter, path, sp[2], toff);
+    }
+    sp[0] = path[0]; sp[1] = path[1];
+#pragma unroll
+    for (int q = 0; q < 6; q++) st[(R3_Y + q) * n] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; q++) { st[(R3_EOLD + q) * n] = 0.f; st[(R3_EINT + q) * n] = 0.f; st[(R3_SP + q) * n] = sp[q]; }
+#pragma unroll
+    for (int q = 0; q < 4; q++) st[(R3_PATH + q) * n] = path[q];
+    st[R3_TOFF * n] = toff;
+    st[R3_ISTEP * n] = __int_as_float(0);
+    if (obs) {
+        float o[5];
+        observe3(p, y, path, sp, o);
+#pragma unroll
+        for (int q = 0; q < 5; q++) obs[i * 5 + q] = o[q];
+    }
+}
+
+hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool zoh, bool flow,
+                            hipStream_t stream) {
+    dim3 grid((unsigned)((io.n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+#define MVRL_L3(PPT, Z, F) hipLaunchKernelGGL((rov3_step_kernel<PPT, Z, F>), grid, block, 0, stream, p, io, fl)
+    if (baked) {
+        if (zoh) { if (flow) MVRL_L3(const Rov3Baked*, true, true); else MVRL_L3(const Rov3Baked*, true, false); }
+        else { if (flow) MVRL_L3(const Rov3Baked*, false, true); else MVRL_L3(const Rov3Baked*, false, false); }
+    } else {
+        if (zoh) { if (flow) MVRL_L3(CP3, true, true); else MVRL_L3(CP3, true, false); }
+        else { if (flow) MVRL_L3(CP3, false, true); else MVRL_L3(CP3, false, false); }
+    }
+#undef MVRL_L3
+    return hipGetLastError();
+}
+
+hipError_t launch_rov3_reset(const Rov3Dev* p, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
+                             uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    hipLaunchKernelGGL(rov3_reset_kernel, grid, block, 0, stream, p, state, n, mask, init, obs, seed, env_offset, epoch,
+                       t_quarter);
+    return hipGetLastError();
+}
+
+}  // namespace mvrl

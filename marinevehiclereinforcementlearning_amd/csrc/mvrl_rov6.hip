@@ -1,0 +1,508 @@
+// mvrl_rov6.hip - BlueROV2 Heavy 6-DoF environment step / reset kernels for gfx950.
+//
+// Replaces BlueROV2Heavy6DoFEnv.step/reset/dataToState + BlueROV2Heavy6DoF.derivs + the PID controller
+// (dynamicsModel_BlueROV2_Heavy_6DoF.py:27-73, :220-442, :467-594) with ONE fused kernel per env step:
+//   set-point from action -> n_sub x RK4 x [PID -> body-frame allocation -> thruster saturation/dead-band ->
+//   Crb/Ca/D/G -> Minv*RHS -> J*nu] -> angle wrap -> observation -> done -> (auto-reset).
+// One lane = one env; state is read once and written once per step (SoA planes, coalesced); everything
+// between lives in VGPRs.  The kernel is VALU-bound (~7 k lane-ops per env step against 300 B of traffic), so
+// the work here is instruction count, not bytes - see DESIGN.md.
+#include "mvrl_kernels.hpp"
+
+namespace mvrl {
+
+struct Trig6 {
+    float sph, cph, sth, cth, sps, cps;
+};
+
+struct Pid6 {
+    float eold[6];
+    float eint[6];
+};
+
+// Body axes iHat/jHat/kHat of updateMovingCoordSystem (6DoF.py:238-242): columns of Rx(phi)Ry(theta)Rz(psi).
+struct Axes {
+    float i0, i1, i2, j0, j1, j2, k0, k1, k2;
+};
+__device__ __forceinline__ Axes body_axes(const Trig6& t) {
+    Axes a;
+    a.i0 = t.cth * t.cps;  a.i1 = t.cph * t.sps + t.sph * t.sth * t.cps;  a.i2 = t.sph * t.sps - t.cph * t.sth * t.cps;
+    a.j0 = -t.cth * t.sps; a.j1 = t.cph * t.cps - t.sph * t.sth * t.sps;  a.j2 = t.sph * t.cps + t.cph * t.sth * t.sps;
+    a.k0 = t.sth;          a.k1 = -t.sph * t.cth;                          a.k2 = t.cph * t.cth;
+    return a;
+}
+
+// ---- PID (6DoF.py:43-73).  HAS_DT: compile-time "t - tOld > 0" (stages 2 and 4 of the RK4 harness); when
+// false the call happens at t == tOld: derivative denominator = the 1e-9 floor and the integral does not move.
+template <bool HAS_DT, class PP>
+__device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6& s, float dtp,
+                                     float inv_den, float* u) {
+    p = launder(p);  // phase-local scalar loads of the constants (see mvrl_device.hpp)
+    float e[6];
+    e[0] = sp[0] - y[0]; e[1] = sp[1] - y[1]; e[2] = sp[2] - y[2];
+    e[3] = sp[3] - y[3]; e[4] = sp[4] - y[4];
+    e[5] = angle_error(sp[5], y[5]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float dedt = (e[i] - s.eold[i]) * inv_den;
+        if (HAS_DT) s.eint[i] = fmaf(0.5f * (s.eold[i] + e[i]), dtp, s.eint[i]);
+        s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
+        float v = fmaf(p->ki[i], s.eint[i], fmaf(p->kd[i], dedt, p->kp[i] * e[i]));
+        u[i] = clampf(v, -p->umax[i], p->umax[i]);
+        s.eold[i] = e[i];
+    }
+}
+
+// thrusterModel(limit(rpm(cv))) (6DoF.py:228, :233-236, :271-275) collapsed in force space: the rpm<->N maps
+// are exact inverses, so saturation is |F| <= f_max and the dead-band is |F| < f_dead -> 0.
+template <class PP>
+__device__ __forceinline__ float limit_force(PP p, float cv) {
+    float f = clampf(cv, -p->f_max, p->f_max);
+    return (fabsf(f) < p->f_dead) ? 0.f : f;
+}
+template <class PP>
+__device__ __forceinline__ float force_to_rpm(PP p, float cv) {
+    return fsign(cv) * sqrtf(fabsf(cv) * p->inv_thrust_k) * 60.f;
+}
+
+// allocateThrust (6DoF.py:220-231) + saturation: global-frame demand u -> limited thruster forces F[8].
+// SYM: the BlueROV2-Heavy layout - Ainv is sparse (horizontal thrusters see X,Y,N; vertical see X,Y,Z,K,M) and its
+// columns are one magnitude times a fixed +-1 pattern, so the 8x6 product collapses to 8 multiplies and a few
+// butterflies (the host verifies the pattern against pinv(A) before selecting this path, mvrl_abi.hip).
+template <bool SYM, class PP>
+__device__ __forceinline__ void allocate6(PP p, const Axes& a, const float* u, float* F, float* cv_raw) {
+    p = launder(p);
+    float b[6];
+    b[0] = u[0] * a.i0 + u[1] * a.i1 + u[2] * a.i2;
+    b[1] = u[0] * a.j0 + u[1] * a.j1 + u[2] * a.j2;
+    b[2] = u[0] * a.k0 + u[1] * a.k1 + u[2] * a.k2;
+    b[3] = u[3] * a.i0 + u[4] * a.i1 + u[5] * a.i2;
+    b[4] = u[3] * a.j0 + u[4] * a.j1 + u[5] * a.j2;
+    b[5] = u[3] * a.k0 + u[4] * a.k1 + u[5] * a.k2;
+    float cv[8];
+    if (SYM) {
+        const float ta = p->sym_ainv[0] * b[0], tb = p->sym_ainv[1] * b[1], tc = p->sym_ainv[2] * b[5];
+        const float pq = tb + tc, mq = tb - tc;
+        cv[0] = ta - pq; cv[1] = ta + pq; cv[2] = -ta - mq; cv[3] = mq - ta;
+        const float tA = fmaf(p->sym_ainv[7], b[4], -p->sym_ainv[3] * b[0]);
+        const float tB = fmaf(p->sym_ainv[6], b[3], p->sym_ainv[4] * b[1]);
+        const float tC = p->sym_ainv[5] * b[2];
+        const float s1 = tB + tC, d1 = tB - tC;
+        cv[4] = tA - s1; cv[5] = -tA - d1; cv[6] = tA + s1; cv[7] = d1 - tA;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            
+            float c = p->Ainv[6 * i] * b[0];
+#pragma unroll
+            for (int j = 1; j < 6; j++) c = fmaf(p->Ainv[6 * i + j], b[j], c);
+            cv[i] = c;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        F[i] = limit_force(p, cv[i]);
+        cv_raw[i] = cv[i];
+    }
+}
+
+// forceModel + solve + kinematics (6DoF.py:253-442) for given limited thruster forces.
+template <bool SYM, bool FLOW, class PP>
+__device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, const Axes& ax,
+                                          const float* F, float2 cur, float* dy) {
+    p = launder(p);
+    const float u = y[6], v = y[7], w = y[8], pp = y[9], q = y[10], r = y[11];
+    float nr0 = u, nr1 = v, nr2 = w;  // relative velocity (only the translational part sees the current)
+    if (FLOW) {
+        nr0 -= cur.x * ax.i0 + cur.y * ax.i1;
+        nr1 -= cur.x * ax.j0 + cur.y * ax.j1;
+        nr2 -= cur.x * ax.k0 + cur.y * ax.k1;
+    }
+    float R[6];
+    if (SYM) {
+        // thrusters: H = A F through the sign-pattern butterflies (see allocate6)
+        const float s01 = F[0] + F[1], d01 = F[1] - F[0], s23 = F[2] + F[3], d23 = F[3] - F[2];
+        const float hA = s01 - s23, hB = d01 + d23, hC = d01 - d23;
+        const float s45 = F[4] + F[5], d45 = F[5] - F[4], s67 = F[6] + F[7], d67 = F[6] - F[7];
+        const float vA = d45 + d67, vB = s67 - s45, vC = d67 - d45;
+        const float H0 = p->sym_a[0] * hA, H1 = p->sym_a[1] * hB, H2 = p->sym_a[2] * vA;
+        const float H3 = fmaf(p->sym_a[4], vB, -p->sym_a[3] * hB);
+        const float H4 = fmaf(p->sym_a[6], vC, p->sym_a[5] * hA);
+        const float H5 = p->sym_a[7] * hC;
+        // rigid-body Coriolis with x_g = y_g = 0, diagonal inertia (6DoF.py:303-332)
+        const float m = p->m, zg = p->cg[2], Ixx = p->I[0], Iyy = p->I[4], Izz = p->I[8];
+        float mzr = m * zg * r, mw = m * w, mv = m * v, mu = m * u;
+        float a2 = m * (zg * pp - v), b2 = m * (zg * q + u);
+        float c0 = mzr * pp + mw * q - mv * r;
+        float c1 = -mw * pp + mzr * q + mu * r;
+        float c2 = -a2 * pp - b2 * q;
+        float c3 = -mzr * u + mw * v + a2 * w + (Izz - Iyy) * q * r;
+        float c4 = -mw * u - mzr * v + b2 * w + (Ixx - Izz) * pp * r;
+        float c5 = mv * u - mu * v + (Iyy - Ixx) * pp * q;
+        // added-mass Coriolis built from nu, applied to nu_r (6DoF.py:334-341, :396)
+        float Xu = p->added[0] * u, Yv = p->added[1] * v, Zw = p->added[2] * w;
+        float Kp = p->added[3] * pp, Mq = p->added[4] * q, Nr = p->added[5] * r;
+        float ca0 = -Zw * q + Yv * r;
+        float ca1 = Zw * pp - Xu * r;
+        float ca2 = -Yv * pp + Xu * q;
+        float ca3 = -Zw * nr1 + Yv * nr2 - Nr * q + Mq * r;
+        float ca4 = Zw * nr0 - Xu * nr2 + Nr * pp - Kp * r;
+        float ca5 = -Yv * nr0 + Xu * nr1 - Mq * pp + Kp * q;
+        // damping: diagonal + the single off-diagonal D[4,2] = -Mww |w| (6DoF.py:345-370)
+        float d0 = fmaf(p->dquad[0], fabsf(u), p->dlin[0]) * nr0;
+        float d1 = fmaf(p->dquad[7], fabsf(v), p->dlin[7]) * nr1;
+        float d2 = fmaf(p->dquad[14], fabsf(w), p->dlin[14]) * nr2;
+        float d3 = fmaf(p->dquad[21], fabsf(pp), p->dlin[21]) * pp;
+        float d4 = fmaf(p->dquad[28], fabsf(q), p->dlin[28]) * q + fmaf(p->dquad[26], fabsf(w), p->dlin[26]) * nr2;
+        float d5 = fmaf(p->dquad[35], fabsf(r), p->dlin[35]) * r;
+        // hydrostatics (6DoF.py:374-388) with x_g = y_g = x_b = y_b = 0
+        float g0 = p->wb * t.sth, g1 = -p->wb * t.cth * t.sph, g2 = -p->wb * t.cth * t.cph;
+        float g3 = p->gw[2] * t.cth * t.sph, g4 = p->gw[2] * t.sth;
+        R[0] = H0 - c0 - ca0 - d0 - g0;
+        R[1] = H1 - c1 - ca1 - d1 - g1;
+        R[2] = H2 - c2 - ca2 - d2 - g2;
+        R[3] = H3 - c3 - ca3 - d3 - g3;
+        R[4] = H4 - c4 - ca4 - d4 - g4;
+        R[5] = H5 - c5 - ca5 - d5;
+        // M^-1 with the (u,q)/(v,p) couplings only (6DoF.py:286-299, :428)
+        dy[6] = p->minv[0] * R[0] + p->minv[4] * R[4];
+        dy[7] = p->minv[7] * R[1] + p->minv[9] * R[3];
+        dy[8] = p->minv[14] * R[2];
+        dy[9] = p->minv[19] * R[1] + p->minv[21] * R[3];
+        dy[10] = p->minv[24] * R[0] + p->minv[28] * R[4];
+        dy[11] = p->minv[35] * R[5];
+    } else {
+        // literal dense form of forceModel (6DoF.py:253-404) for arbitrary constants
+        const float vel[6] = {u, v, w, pp, q, r};
+        const float vr[6] = {nr0, nr1, nr2, pp, q, r};
+        const float m = p->m, xg = p->cg[0], yg = p->cg[1], zg = p->cg[2];
+        const float Ixx = p->I[0], Ixy = p->I[1], Ixz = p->I[2], Iyy = p->I[4], Iyz = p->I[5], Izz = p->I[8];
+        float Crb[36] = {
+            0, 0, 0, m * (yg * q + zg * r), -m * (xg * q - w), -m * (xg * r + v),
+            0, 0, 0, -m * (yg * pp + w), m * (zg * r + xg * pp), -m * (yg * r - u),
+            0, 0, 0, -m * (zg * pp - v), -m * (zg * q + u), m * (xg * pp + yg * q),
+            -m * (yg * q + zg * r), m * (yg * pp + w), m * (zg * pp - v), 0, -Iyz * q - Ixz * pp + Izz * r, Iyz * r + Ixy * pp - Iyy * q,
+            m * (xg * q - w), -m * (zg * r + xg * pp), m * (zg * q + u), Iyz * q + Ixz * pp - Izz * r, 0, -Ixz * r - Ixy * q + Ixx * pp,
+            m * (xg * r + v), m * (yg * r - u), -m * (xg * pp + yg * q), -Iyz * r - Ixy * pp + Iyy * q, Ixz * r + Ixy * q - Ixx * pp, 0};
+        float Xud = p->added[0], Yvd = p->added[1], Zwd = p->added[2], Kpd = p->added[3], Mqd = p->added[4], Nrd = p->added[5];
+        float Ca[36] = {
+            0, 0, 0, 0, -Zwd * w, Yvd * v,
+            0, 0, 0, Zwd * w, 0, -Xud * u,
+            0, 0, 0, -Yvd * v, Xud * u, 0,
+            0, -Zwd * w, Yvd * v, 0, -Nrd * r, Mqd * q,
+            Zwd * w, 0, -Xud * u, Nrd * r, 0, -Kpd * pp,
+            -Yvd * v, Xud * u, 0, -Mqd * q, Kpd * pp, 0};
+        float G[6] = {p->wb * t.sth, -p->wb * t.cth * t.sph, -p->wb * t.cth * t.cph,
+                      -p->gw[1] * t.cth * t.cph + p->gw[2] * t.cth * t.sph,
+                      p->gw[2] * t.sth + p->gw[0] * t.cth * t.cph,
+                      -p->gw[0] * t.cth * t.sph - p->gw[1] * t.sth};
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float h = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) h = fmaf(p->A[8 * i + k], F[k], h);
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                c1 = fmaf(Crb[6 * i + j], vel[j], c1);
+                float dij = fmaf(p->dquad[6 * i + j], fabsf(vel[j]), p->dlin[6 * i + j]);
+                c2 = fmaf(Ca[6 * i + j] + dij, vr[j], c2);
+            }
+            R[i] = -c1 - c2 - G[i] + h;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) a = fmaf(p->minv[6 * i + j], R[j], a);
+            dy[6 + i] = a;
+        }
+    }
+    // eta_dot = J(eta) nu (resources.py:98-143) - with the reference's J1[0,2] = s(psi)s(phi) + c(psi)s(theta)s(phi)
+    // and the cos(theta) guard (:116-120)
+    float cd = t.cth;
+    cd = (fabsf(cd) < 1e-12f) ? 1e-6f : ((fabsf(cd) < 1e-6f) ? 1e-6f * fsign(cd) : cd);
+    float icd = 1.0f / cd;
+    float cpsst = t.cps * t.sth, spsst = t.sps * t.sth;
+    dy[0] = t.cps * t.cth * u + (-t.sps * t.cph + cpsst * t.sph) * v + (t.sps * t.sph + cpsst * t.sph) * w;
+    dy[1] = t.sps * t.cth * u + (t.cps * t.cph + spsst * t.sph) * v + (-t.cps * t.sph + spsst * t.cph) * w;
+    dy[2] = -t.sth * u + t.cth * t.sph * v + t.cth * t.cph * w;
+    float tq = t.sph * q + t.cph * r;
+    dy[3] = pp + t.sth * icd * tq;
+    dy[4] = t.cph * q - t.sph * r;
+    dy[5] = icd * tq;
+}
+
+__device__ __forceinline__ Trig6 trig6(const float* y) {
+    Trig6 t;
+    sincos_f32(y[3], t.sph, t.cph);
+    sincos_f32(y[4], t.sth, t.cth);
+    sincos_f32(y[5], t.sps, t.cps);
+    return t;
+}
+
+// One RHS evaluation in FAITHFUL mode = BlueROV2Heavy6DoF.derivs (6DoF.py:406-442), PID state mutated.
+template <bool SYM, bool FLOW, bool HAS_DT, class PP>
+__device__ __forceinline__ void derivs6(PP p, const float* y, const float* sp, Pid6& pid, float dtp,
+                                        float inv_den, float2 cur, float* dy, float* gcf, float* cv_raw, bool keep) {
+    Trig6 t = trig6(y);
+    Axes ax = body_axes(t);
+    float u[6], F[8], cv[8];
+    pid6<HAS_DT>(p, y, sp, pid, dtp, inv_den, u);
+    allocate6<SYM>(p, ax, u, F, cv);
+    if (keep) {  // wave-uniform: side outputs of the last RHS call of the step (timeHistory columns)
+#pragma unroll
+        for (int i = 0; i < 6; i++) gcf[i] = u[i];
+#pragma unroll
+        for (int i = 0; i < 8; i++) cv_raw[i] = cv[i];
+    }
+    dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, dy);
+}
+
+template <bool SYM, bool FLOW, class PP>
+__device__ __forceinline__ void dynamics_only6(PP p, const float* y, const float* F, float2 cur, float* dy) {
+    Trig6 t = trig6(y);
+    Axes ax = body_axes(t);
+    dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, dy);
+}
+
+// dataToState (6DoF.py:467-483)
+template <class PP>
+__device__ __forceinline__ void observe6(PP p, const float* y, const float* path, const float* sp, float* o) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o[k] = clampf((path[k] - y[k]) * p->inv_obs_pos, -1.f, 1.f);
+        o[3 + k] = clampf((path[3 + k] - y[k]) * p->inv_obs_pos, -1.f, 1.f);
+        o[6 + k] = clampf(angle_error(sp[3 + k], y[3 + k]) * p->inv_obs_ang, -1.f, 1.f);
+    }
+}
+
+// Random episode initialisation.  The reference's own random branch is broken for 6-DoF (6DoF.py:497 raises);
+// this is the 3-DoF recipe (3DoF.py:423-424) extended to three coordinates: path = (U-0.5)*10, attitude = U*2pi.
+__device__ __forceinline__ void random_init6(uint64_t seed, int64_t gid, uint32_t epoch, float t_quarter, float* path,
+                                             float* ang, float& toffset) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t g0 = (uint32_t)gid, g1 = (uint32_t)((uint64_t)gid >> 32);
+    Philox4 r0 = philox4x32_10(g0, g1, epoch, 0u, k0, k1);
+    Philox4 r1 = philox4x32_10(g0, g1, epoch, 1u, k0, k1);
+    Philox4 r2 = philox4x32_10(g0, g1, epoch, 2u, k0, k1);
+    path[0] = (u01(r0.v[0]) - 0.5f) * 10.f; path[1] = (u01(r0.v[1]) - 0.5f) * 10.f; path[2] = (u01(r0.v[2]) - 0.5f) * 10.f;
+    path[3] = (u01(r0.v[3]) - 0.5f) * 10.f; path[4] = (u01(r1.v[0]) - 0.5f) * 10.f; path[5] = (u01(r1.v[1]) - 0.5f) * 10.f;
+    ang[0] = u01(r1.v[2]) * MVRL_TWO_PI_HI; ang[1] = u01(r1.v[3]) * MVRL_TWO_PI_HI; ang[2] = u01(r2.v[0]) * MVRL_TWO_PI_HI;
+    toffset = u01(r2.v[1]) * t_quarter;
+}
+
+enum { R6_Y = 0, R6_EOLD = 12, R6_EINT = 18, R6_SP = 24, R6_PATH = 30, R6_TOFF = 36, R6_ISTEP = 37, R6_WORDS = 38 };
+
+template <class PP, bool SYM, bool ZOH, bool FLOW>
+__global__ __launch_bounds__(MVRL_BLOCK) void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
+    const PP p = param_ptr<PP>(pg);
+    const uint32_t i = blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= (uint32_t)io.n) return;
+    // plane k of env i = state[k * n + i] with a 32-bit element index: the access lowers to the
+    // `global_load_dword v, v_off, s[base:base+1]` form (uniform 64-bit base in SGPRs + one 32-bit VGPR offset)
+    // instead of a 64-bit VGPR address pair per plane.  The host guarantees words * n < 2^30.
+    const uint32_t n32 = (uint32_t)io.n;
+    char* const stb = reinterpret_cast<char*>(io.state);
+#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) << 2)))
+
+    float y[12], sp[6], path[6];
+    Pid6 pid;
+#pragma unroll
+    for (int k = 0; k < 12; k++) y[k] = ST(R6_Y + k);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { pid.eold[k] = ST(R6_EOLD + k); pid.eint[k] = ST(R6_EINT + k); }
+#pragma unroll
+    for (int k = 0; k < 6; k++) path[k] = ST(R6_PATH + k);
+    int istep = __float_as_int(ST(R6_ISTEP));
+
+    if (io.fixed_sp) {  // 6DoF.py:536-541
+#pragma unroll
+        for (int k = 0; k < 6; k++) sp[k] = ST(R6_SP + k);
+    } else {            // 6DoF.py:545-552
+        const float2* ap = reinterpret_cast<const float2*>(io.actions + (size_t)i * 6);
+        float2 a01 = ap[0], a23 = ap[1], a45 = ap[2];
+        sp[0] = fmaf(a01.x, p->act_scale[0], y[0]); sp[1] = fmaf(a01.y, p->act_scale[1], y[1]);
+        sp[2] = fmaf(a23.x, p->act_scale[2], y[2]); sp[3] = fmaf(a23.y, p->act_scale[3], y[3]);
+        sp[4] = fmaf(a45.x, p->act_scale[4], y[4]); sp[5] = fmaf(a45.y, p->act_scale[5], y[5]);
+    }
+    const bool first = (istep == 0);  // controller.eOld is None until the first call (6DoF.py:62-63)
+    istep += 1;                       // 6DoF.py:533
+
+    float2 cur = make_float2(0.f, 0.f);
+    if (FLOW) {  // sampled once per env step at the pre-step position, time AFTER the increment
+        float toff = ST(R6_TOFF);
+        cur = flow_interp_uv(fl, (float)istep * io.dt + toff, y[0], y[1]);
+    }
+    if (first) {
+        pid.eold[0] = sp[0] - y[0]; pid.eold[1] = sp[1] - y[1]; pid.eold[2] = sp[2] - y[2];
+        pid.eold[3] = sp[3] - y[3]; pid.eold[4] = sp[4] - y[4]; pid.eold[5] = angle_error(sp[5], y[5]);
+    }
+
+    const float h = io.dt / (float)io.n_sub;
+    const float hh = 0.5f * h, h6 = h / 6.f;
+    const float inv_hh = 1.0f / hh;
+    float gcf[6] = {0, 0, 0, 0, 0, 0}, cvr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool want_aux = (io.aux != nullptr);
+    for (int ks = 0; ks < io.n_sub; ks++) {
+        float k[12], acc[12], yt[12];
+        const bool last = want_aux && (ks == io.n_sub - 1);
+        if (ZOH) {
+            // PID + allocation once per sub-step; t - tOld = h except for the very first call after reset (= 0)
+            Trig6 t = trig6(y);
+            Axes ax = body_axes(t);
+            float u[6], F[8];
+            const bool very_first = first && (ks == 0);
+            if (very_first) pid6<false>(p, y, sp, pid, 0.f, 1e9f, u);
+            else pid6<true>(p, y, sp, pid, h, 1.0f / h, u);
+            allocate6<SYM>(p, ax, u, F, cvr);
+#pragma unroll
+            for (int q = 0; q < 6; q++) gcf[q] = u[q];
+            dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, k);
+#pragma unroll
+            for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
+            dynamics_only6<SYM, FLOW>(p, yt, F, cur, k);
+#pragma unroll
+            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
+            dynamics_only6<SYM, FLOW>(p, yt, F, cur, k);
+#pragma unroll
+            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
+            dynamics_only6<SYM, FLOW>(p, yt, F, cur, k);
+        } else {
+            // stage times: t, t+h/2, t+h/2, t+h  ->  t - tOld = 0, h/2, 0, h/2 (the previous call was at t)
+            derivs6<SYM, FLOW, false>(p, y, sp, pid, 0.f, 1e9f, cur, k, gcf, cvr, false);
+#pragma unroll
+            for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
+            derivs6<SYM, FLOW, true>(p, yt, sp, pid, hh, inv_hh, cur, k, gcf, cvr, false);
+#pragma unroll
+            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
+            derivs6<SYM, FLOW, false>(p, yt, sp, pid, 0.f, 1e9f, cur, k, gcf, cvr, false);
+#pragma unroll
+            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
+            derivs6<SYM, FLOW, true>(p, yt, sp, pid, hh, inv_hh, cur, k, gcf, cvr, last);
+        }
+#pragma unroll
+        for (int q = 0; q < 12; q++) y[q] = fmaf(h6, acc[q] + k[q], y[q]);
+    }
+    // 6DoF.py:560
+    y[3] = mod_two_pi(y[3]); y[4] = mod_two_pi(y[4]); y[5] = mod_two_pi(y[5]);
+
+    float o[9];
+    observe6(p, y, path, sp, o);
+    const bool done = istep >= io.max_steps;  // 6DoF.py:569-571
+
+    if (want_aux) {  // timeHistory columns F0..F5, u0..u7 (6DoF.py:578-587)
+        float* ax = io.aux + (size_t)i * 14;
+#pragma unroll
+        for (int q = 0; q < 6; q++) ax[q] = gcf[q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) ax[6 + q] = force_to_rpm(p, cvr[q]);
+    }
+    io.reward[i] = 0.f;  // 6DoF.py:575
+    io.done[i] = done ? 1 : 0;
+
+    if (done && io.auto_reset) {
+        // SB3 VecEnv semantics: keep the terminal observation, hand back the first observation of a new episode
+        if (io.term_obs) {
+#pragma unroll
+            for (int q = 0; q < 9; q++) io.term_obs[(size_t)i * 9 + q] = o[q];
+        }
+        float ang[3], toff;
+        if (io.fixed_sp) {
+            // reset(initialSetpoint=sp) keeps the set-point: path/sp stay (6DoF.py:500-511)
+#pragma unroll
+            for (int q = 0; q < 3; q++) { ang[q] = sp[3 + q]; }
+            toff = FLOW ? ST(R6_TOFF) : 0.f;
+        } else {
+            random_init6(io.seed, io.env_offset + (int64_t)i, io.epoch, fl.t_quarter, path, ang, toff);
+#pragma unroll
+            for (int q = 0; q < 6; q++) ST(R6_PATH + q) = path[q];
+            ST(R6_TOFF) = toff;
+            sp[0] = path[0]; sp[1] = path[1]; sp[2] = path[2]; sp[3] = ang[0]; sp[4] = ang[1]; sp[5] = ang[2];
+        }
+#pragma unroll
+        for (int q = 0; q < 12; q++) y[q] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; q++) { pid.eold[q] = 0.f; pid.eint[q] = 0.f; }
+        istep = 0;
+        observe6(p, y, path, sp, o);
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) io.obs[(size_t)i * 9 + q] = o[q];
+#pragma unroll
+    for (int k = 0; k < 12; k++) ST(R6_Y + k) = y[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { ST(R6_EOLD + k) = pid.eold[k]; ST(R6_EINT + k) = pid.eint[k]; }
+    if (!io.fixed_sp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) ST(R6_SP + k) = sp[k];
+    }
+    ST(R6_ISTEP) = __int_as_float(istep);
+}
+
+// reset (6DoF.py:485-529): mask/init may be null.
+__global__ __launch_bounds__(MVRL_BLOCK) void rov6_reset_kernel(const Rov6Dev* __restrict__ pg, float* state, int64_t n, const uint8_t* mask,
+                                                                const float* init, float* obs, uint64_t seed,
+                                                                int64_t env_offset, uint32_t epoch, float t_quarter) {
+    const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (mask && !mask[i]) return;
+    const CP6 p = as_const(pg);
+    float* st = state + i;
+    float path[6], sp[6], y[12], toff = 0.f;
+    if (init) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) path[q] = init[i * 9 + q];
+        sp[0] = path[0]; sp[1] = path[1]; sp[2] = path[2];
+        sp[3] = init[i * 9 + 6]; sp[4] = init[i * 9 + 7]; sp[5] = init[i * 9 + 8];
+    } else {
+        float ang[3];
+        random_init6(seed, env_offset + i, epoch, t_quarter, path, ang, toff);
+        sp[0] = path[0]; sp[1] = path[1]; sp[2] = path[2]; sp[3] = ang[0]; sp[4] = ang[1]; sp[5] = ang[2];
+    }
+#pragma unroll
+    for (int q = 0; q < 12; q++) { y[q] = 0.f; st[(R6_Y + q) * n] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        st[(R6_EOLD + q) * n] = 0.f; st[(R6_EINT + q) * n] = 0.f;
+        st[(R6_SP + q) * n] = sp[q]; st[(R6_PATH + q) * n] = path[q];
+    }
+    st[R6_TOFF * n] = toff;
+    st[R6_ISTEP * n] = __int_as_float(0);
+    if (obs) {
+        float o[9];
+        observe6(p, y, path, sp, o);
+#pragma unroll
+        for (int q = 0; q < 9; q++) obs[i * 9 + q] = o[q];
+    }
+}
+
+// ---- host-side launchers ---------------------------------------------------------------------------
+hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool sym, bool zoh,
+                            bool flow, hipStream_t stream) {
+    dim3 grid((unsigned)((io.n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+#define MVRL_L6(S, Z, F) hipLaunchKernelGGL((rov6_step_kernel<CP6, S, Z, F>), grid, block, 0, stream, p, io, fl)
+#define MVRL_L6B(Z, F) hipLaunchKernelGGL((rov6_step_kernel<const Rov6Baked*, true, Z, F>), grid, block, 0, stream, p, io, fl)
+    if (baked) {
+        if (zoh) { if (flow) MVRL_L6B(true, true); else MVRL_L6B(true, false); }
+        else { if (flow) MVRL_L6B(false, true); else MVRL_L6B(false, false); }
+    } else if (sym) {
+        if (zoh) { if (flow) MVRL_L6(true, true, true); else MVRL_L6(true, true, false); }
+        else { if (flow) MVRL_L6(true, false, true); else MVRL_L6(true, false, false); }
+    } else {
+        if (zoh) { if (flow) MVRL_L6(false, true, true); else MVRL_L6(false, true, false); }
+        else { if (flow) MVRL_L6(false, false, true); else MVRL_L6(false, false, false); }
+    }
+#undef MVRL_L6
+#undef MVRL_L6B
+    return hipGetLastError();
+}
+
+hipError_t launch_rov6_reset(const Rov6Dev* p, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
+                             uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    hipLaunchKernelGGL(rov6_reset_kernel, grid, block, 0, stream, p, state, n, mask, init, obs, seed, env_offset, epoch,
+                       t_quarter);
+    return hipGetLastError();
+}
+
+}  // namespace mvrl

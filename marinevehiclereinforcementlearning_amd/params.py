@@ -18,7 +18,7 @@ ABI_VERSION = 1
 
 MODEL_NAMES = {"auv": MODEL_AUV, "rov3": MODEL_ROV3, "rov6": MODEL_ROV6}
 #            act, obs, init, state_words, aux
-MODEL_DIMS = {MODEL_AUV: (3, 11, 16, 54, 11), MODEL_ROV3: (3, 5, 5, 20, 7), MODEL_ROV6: (6, 9, 9, 37, 14)}
+MODEL_DIMS = {MODEL_AUV: (3, 11, 16, 53, 11), MODEL_ROV3: (3, 5, 5, 21, 7), MODEL_ROV6: (6, 9, 9, 38, 14)}
 
 d = C.c_double
 
