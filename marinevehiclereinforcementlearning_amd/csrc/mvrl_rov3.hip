@@ -13,15 +13,23 @@ struct Pid3 {
 };
 
 // PID + body-frame resolution + allocation + saturation (3DoF.py:141-180) -> limited thruster forces F[4]
-template <bool HAS_DT, class PP>
+// USE_INC / dpose: see pid6 in mvrl_rov6.hip - the error difference of two nearby RK stages is taken from the
+// stage slopes, not from the rounded fp32 states.
+template <bool HAS_DT, bool USE_INC, class PP>
 __device__ __forceinline__ void control3(PP p, const float* y, const float* sp, Pid3& s, float dtp, float inv_den,
-                                         float c, float sn, float* F, float* gcf, float* cv_raw, bool keep) {
+                                         const float* dpose, float c, float sn, float* F, float* gcf, float* cv_raw,
+                                         bool keep) {
     p = launder(p);
     float e[3] = {sp[0] - y[0], sp[1] - y[1], angle_error(sp[2], y[2])};
     float u[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        float dedt = (e[i] - s.eold[i]) * inv_den;
+        float de = e[i] - s.eold[i];
+        if (USE_INC) {
+            const float di = -dpose[i];
+            de = (fabsf(de - di) <= 1e-5f) ? di : de;
+        }
+        float dedt = de * inv_den;
         if (HAS_DT) s.eint[i] = fmaf(0.5f * (s.eold[i] + e[i]), dtp, s.eint[i]);
         s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
         float v = fmaf(p->ki[i], s.eint[i], fmaf(p->kd[i], dedt, p->kp[i] * e[i]));
@@ -88,11 +96,11 @@ __device__ __forceinline__ void dynamics3(PP p, const float* y, float c, float s
 
 template <bool FLOW, bool HAS_DT, class PP>
 __device__ __forceinline__ void derivs3(PP p, const float* y, const float* sp, Pid3& pid, float dtp, float inv_den,
-                                        float2 cur, float* dy, float* gcf, float* cv_raw, bool keep) {
+                                        const float* dpose, float2 cur, float* dy, float* gcf, float* cv_raw, bool keep) {
     float sn, c;
     sincos_f32(y[2], sn, c);
     float F[4];
-    control3<HAS_DT>(p, y, sp, pid, dtp, inv_den, c, sn, F, gcf, cv_raw, keep);
+    control3<HAS_DT, true>(p, y, sp, pid, dtp, inv_den, dpose, c, sn, F, gcf, cv_raw, keep);
     dynamics3<FLOW>(p, y, c, sn, F, cur, dy);
 }
 
@@ -155,14 +163,15 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_step_kernel(const Rov3Dev* __
     const float h = io.dt / (float)io.n_sub, hh = 0.5f * h, h6 = h / 6.f, inv_hh = 1.0f / hh;
     float gcf[3] = {0, 0, 0}, cvr[4] = {0, 0, 0, 0};
     const bool want_aux = (io.aux != nullptr);
+    float inc_prev[3] = {1e30f, 1e30f, 1e30f};  // see mvrl_rov6.hip
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[6], acc[6], yt[6];
         const bool last = want_aux && (ks == io.n_sub - 1);
         if (ZOH) {
             float sn, c, F[4];
             sincos_f32(y[2], sn, c);
-            if (first && ks == 0) control3<false>(p, y, sp, pid, 0.f, 1e9f, c, sn, F, gcf, cvr, true);
-            else control3<true>(p, y, sp, pid, h, 1.0f / h, c, sn, F, gcf, cvr, true);
+            if (first && ks == 0) control3<false, false>(p, y, sp, pid, 0.f, 1e9f, nullptr, c, sn, F, gcf, cvr, true);
+            else control3<true, false>(p, y, sp, pid, h, 1.0f / h, nullptr, c, sn, F, gcf, cvr, true);
             dynamics3<FLOW>(p, y, c, sn, F, cur, k);
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
@@ -177,16 +186,27 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_step_kernel(const Rov3Dev* __
             sincos_f32(yt[2], sn, c);
             dynamics3<FLOW>(p, yt, c, sn, F, cur, k);
         } else {
-            derivs3<FLOW, false>(p, y, sp, pid, 0.f, 1e9f, cur, k, gcf, cvr, false);
+            float dp[3], d2[3], d3[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) dp[q] = inc_prev[q];
+            derivs3<FLOW, false>(p, y, sp, pid, 0.f, 1e9f, dp, cur, k, gcf, cvr, false);
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
-            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, cur, k, gcf, cvr, false);
+#pragma unroll
+            for (int q = 0; q < 3; q++) dp[q] = hh * k[q];
+            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, dp, cur, k, gcf, cvr, false);
+#pragma unroll
+            for (int q = 0; q < 3; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
-            derivs3<FLOW, false>(p, yt, sp, pid, 0.f, 1e9f, cur, k, gcf, cvr, false);
+            derivs3<FLOW, false>(p, yt, sp, pid, 0.f, 1e9f, dp, cur, k, gcf, cvr, false);
+#pragma unroll
+            for (int q = 0; q < 3; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
-            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, cur, k, gcf, cvr, last);
+            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, dp, cur, k, gcf, cvr, last);
+#pragma unroll
+            for (int q = 0; q < 3; q++) inc_prev[q] = h6 * (acc[q] + k[q]) - d3[q];
         }
 #pragma unroll
         for (int q = 0; q < 6; q++) y[q] = fmaf(h6, acc[q] + k[q], y[q]);

@@ -34,9 +34,17 @@ __device__ __forceinline__ Axes body_axes(const Trig6& t) {
 
 // ---- PID (6DoF.py:43-73).  HAS_DT: compile-time "t - tOld > 0" (stages 2 and 4 of the RK4 harness); when
 // false the call happens at t == tOld: derivative denominator = the 1e-9 floor and the integral does not move.
-template <bool HAS_DT, class PP>
+//
+// USE_INC: the caller knows by how much the pose moved since the previous PID call (`dpose`, built from the RK
+// stage increments h*k, not from the rounded states).  The reference forms e - eOld in fp64, where the rounding of
+// the two states (1e-16) is far below the smallest increment that matters, 2.5e-9 (K_D * de / 1e-9 against the
+// clamp).  In fp32 the states are only resolved to ~1e-7, so e - eOld of two nearby stages would be rounding
+// noise times 1e9.  -dpose IS that difference (the set-point is constant inside a step), accurate to 1e-7
+// relative; it is used whenever it agrees with the rounded difference (it does not across a yaw-error branch
+// change, where the rounded difference is the right one).
+template <bool HAS_DT, bool USE_INC, class PP>
 __device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6& s, float dtp,
-                                     float inv_den, float* u) {
+                                     float inv_den, const float* dpose, float* u) {
     p = launder(p);  // phase-local scalar loads of the constants (see mvrl_device.hpp)
     float e[6];
     e[0] = sp[0] - y[0]; e[1] = sp[1] - y[1]; e[2] = sp[2] - y[2];
@@ -44,7 +52,12 @@ __device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6
     e[5] = angle_error(sp[5], y[5]);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        float dedt = (e[i] - s.eold[i]) * inv_den;
+        float de = e[i] - s.eold[i];
+        if (USE_INC) {
+            const float di = -dpose[i];
+            de = (fabsf(de - di) <= 1e-5f) ? di : de;
+        }
+        float dedt = de * inv_den;
         if (HAS_DT) s.eint[i] = fmaf(0.5f * (s.eold[i] + e[i]), dtp, s.eint[i]);
         s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
         float v = fmaf(p->ki[i], s.eint[i], fmaf(p->kd[i], dedt, p->kp[i] * e[i]));
@@ -241,13 +254,13 @@ __device__ __forceinline__ Trig6 trig6(const float* y) {
 }
 
 // One RHS evaluation in FAITHFUL mode = BlueROV2Heavy6DoF.derivs (6DoF.py:406-442), PID state mutated.
-template <bool SYM, bool FLOW, bool HAS_DT, class PP>
-__device__ __forceinline__ void derivs6(PP p, const float* y, const float* sp, Pid6& pid, float dtp,
-                                        float inv_den, float2 cur, float* dy, float* gcf, float* cv_raw, bool keep) {
+template <bool SYM, bool FLOW, bool HAS_DT, bool USE_INC, class PP>
+__device__ __forceinline__ void derivs6(PP p, const float* y, const float* sp, Pid6& pid, float dtp, float inv_den,
+                                        const float* dpose, float2 cur, float* dy, float* gcf, float* cv_raw, bool keep) {
     Trig6 t = trig6(y);
     Axes ax = body_axes(t);
     float u[6], F[8], cv[8];
-    pid6<HAS_DT>(p, y, sp, pid, dtp, inv_den, u);
+    pid6<HAS_DT, USE_INC>(p, y, sp, pid, dtp, inv_den, dpose, u);
     allocate6<SYM>(p, ax, u, F, cv);
     if (keep) {  // wave-uniform: side outputs of the last RHS call of the step (timeHistory columns)
 #pragma unroll
@@ -343,6 +356,9 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_step_kernel(const Rov6Dev* __
     const float inv_hh = 1.0f / hh;
     float gcf[6] = {0, 0, 0, 0, 0, 0}, cvr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool want_aux = (io.aux != nullptr);
+    // pose increment between the last PID call of a sub-step and the first of the next; not known across env steps
+    // (new set-point, angle wrap): 1e30 fails pid6's consistency test, which then uses the rounded difference
+    float inc_prev[6] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[12], acc[12], yt[12];
         const bool last = want_aux && (ks == io.n_sub - 1);
@@ -352,8 +368,8 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_step_kernel(const Rov6Dev* __
             Axes ax = body_axes(t);
             float u[6], F[8];
             const bool very_first = first && (ks == 0);
-            if (very_first) pid6<false>(p, y, sp, pid, 0.f, 1e9f, u);
-            else pid6<true>(p, y, sp, pid, h, 1.0f / h, u);
+            if (very_first) pid6<false, false>(p, y, sp, pid, 0.f, 1e9f, nullptr, u);
+            else pid6<true, false>(p, y, sp, pid, h, 1.0f / h, nullptr, u);
             allocate6<SYM>(p, ax, u, F, cvr);
 #pragma unroll
             for (int q = 0; q < 6; q++) gcf[q] = u[q];
@@ -368,17 +384,31 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_step_kernel(const Rov6Dev* __
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
             dynamics_only6<SYM, FLOW>(p, yt, F, cur, k);
         } else {
-            // stage times: t, t+h/2, t+h/2, t+h  ->  t - tOld = 0, h/2, 0, h/2 (the previous call was at t)
-            derivs6<SYM, FLOW, false>(p, y, sp, pid, 0.f, 1e9f, cur, k, gcf, cvr, false);
+            // stage times: t, t+h/2, t+h/2, t+h  ->  t - tOld = 0, h/2, 0, h/2 (the previous call was at t).
+            // dp = pose increment since the previous PID call, from the stage slopes (see pid6).
+            float dp[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) dp[q] = inc_prev[q];  // 1e30 on the first stage of the env step: "unknown"
+            derivs6<SYM, FLOW, false, true>(p, y, sp, pid, 0.f, 1e9f, dp, cur, k, gcf, cvr, false);
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
-            derivs6<SYM, FLOW, true>(p, yt, sp, pid, hh, inv_hh, cur, k, gcf, cvr, false);
+#pragma unroll
+            for (int q = 0; q < 6; q++) dp[q] = hh * k[q];                       // (y + hh k1) - y
+            derivs6<SYM, FLOW, true, true>(p, yt, sp, pid, hh, inv_hh, dp, cur, k, gcf, cvr, false);
+            float d2[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }  // hh (k2 - k1)
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
-            derivs6<SYM, FLOW, false>(p, yt, sp, pid, 0.f, 1e9f, cur, k, gcf, cvr, false);
+            derivs6<SYM, FLOW, false, true>(p, yt, sp, pid, 0.f, 1e9f, dp, cur, k, gcf, cvr, false);
+            float d3[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }          // h k3 - hh k2
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
-            derivs6<SYM, FLOW, true>(p, yt, sp, pid, hh, inv_hh, cur, k, gcf, cvr, last);
+            derivs6<SYM, FLOW, true, true>(p, yt, sp, pid, hh, inv_hh, dp, cur, k, gcf, cvr, last);
+#pragma unroll
+            for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (acc[q] + k[q]) - d3[q];            // y_new - (y + h k3)
         }
 #pragma unroll
         for (int q = 0; q < 12; q++) y[q] = fmaf(h6, acc[q] + k[q], y[q]);
