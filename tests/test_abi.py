@@ -1,0 +1,100 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, exports every symbol the header
+declares, and refuses to compute without a GPU (no silent CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from .conftest import REPO
+from marinevehiclereinforcementlearning_amd import _lib, build, params as P
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_lib()
+    return _lib.load()
+
+
+def header_symbols():
+    txt = open(os.path.join(REPO, "include", "mvrl.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mvrl_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"libmvrl.so does not export {s}"
+    assert sorted(_lib.SYMBOLS) == syms  # the Python binding covers exactly the header
+
+
+def test_abi_version_and_dims(lib):
+    assert lib.mvrl_abi_version() == P.ABI_VERSION
+    for model, (act, obs, init, words, aux) in P.MODEL_DIMS.items():
+        a, o, i, w = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        assert lib.mvrl_model_dims(model, C.byref(a), C.byref(o), C.byref(i), C.byref(w)) == 0
+        assert (a.value, o.value, i.value, w.value) == (act, obs, init, words)
+        assert lib.mvrl_aux_dim(model) == aux
+    assert lib.mvrl_model_dims(7, None, None, None, None) == -1
+
+
+def test_struct_layouts_match_header(lib):
+    """sizeof() of the ctypes mirrors == the C structs (checked by compiling a probe with gcc)."""
+    import subprocess
+    import tempfile
+    src = '#include <stdio.h>\n#include "mvrl.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(mvrl_rov6_params), ' \
+          'sizeof(mvrl_rov3_params), sizeof(mvrl_auv_params), sizeof(mvrl_flow_desc), sizeof(mvrl_config));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")])
+        out = subprocess.check_output([os.path.join(d, "p")]).split()
+    sizes = [int(x) for x in out]
+    assert sizes == [C.sizeof(P.Rov6Params), C.sizeof(P.Rov3Params), C.sizeof(P.AuvParams), C.sizeof(P.FlowDesc),
+                     C.sizeof(P.Config)]
+
+
+def test_bad_config_is_rejected(lib):
+    cfg = P.make_config("rov6", 16)
+    cfg.abi_version = 99
+    h = C.c_void_p()
+    assert lib.mvrl_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"ABI" in lib.mvrl_last_error(None)
+    cfg = P.make_config("rov6", 0)
+    assert lib.mvrl_create(C.byref(cfg), C.byref(h)) == -1
+    cfg = P.make_config("rov6", 40_000_000)  # 38 words * n >= 2^30
+    assert lib.mvrl_create(C.byref(cfg), C.byref(h)) == -1
+    cfg = P.make_config("rov3", 8, n_substeps=0)
+    assert lib.mvrl_create(C.byref(cfg), C.byref(h)) == -1
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    """On a box without a HIP device the product path must fail loudly (MVRL_ENODEV), never compute on the CPU."""
+    if lib.mvrl_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.MvrlError, match="ENODEV"):
+        _lib.Handle(P.make_config("rov6", 8))
+    with pytest.raises(_lib.MvrlError, match="ENODEV"):
+        _lib.flow_interp(np.zeros((2, 2, 2, 3), np.float32), 1, 1, 1, [0.], [0.], [0.])
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may import/reference it."""
+    pkg = os.path.join(REPO, "marinevehiclereinforcementlearning_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".inc")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle" not in txt.lower() or f == "_never_.py", f"{f} mentions the oracle"
+
+
+def test_baked_table_matches_params():
+    """csrc/mvrl_baked.inc is regenerated from params.py; SYM structure detection agrees with the defaults."""
+    from marinevehiclereinforcementlearning_amd import devparams as D
+    assert D.rov6_structured(P.rov6_params())
+    assert not D.rov6_structured(P.rov6_params(CG=[0.01, 0., 0.05]))
+    assert not D.rov6_structured(P.rov6_params(l_x=0.15, l_y=0.101, Yr=0.3))
+    sa, sb = D.sym_layout(P.rov6_params().alloc, P.rov6_params().alloc_inv)
+    assert abs(sa[0] - 0.838671) < 1e-6 and abs(sb[7] - 2.083333) < 1e-6
