@@ -180,7 +180,9 @@ int mvrl_reset_dev(mvrl_handle* h, const uint8_t* mask_dev, const float* init_de
 
 /* ---- step: replaces Env.step (6DoF.py:531-594, 3DoF.py:455-514, verySimpleAuv.py:264-410) -------------
  * and SB3 VecEnv.step_async/step_wait (called at tag/main_00_sbl.py:145-161 through agent.learn).
- * actions [n_envs, act_dim] f32 ; obs [n_envs, obs_dim] f32 ; reward [n_envs] f32 ; done [n_envs] u8. */
+ * actions [n_envs, act_dim] f32 ; obs [n_envs, obs_dim] f32 ; reward [n_envs] f32 ; done [n_envs] u8:
+ * 0 = running, non-zero = done; bit 1 (value 2) is set when the episode ended on the time limit (SB3's
+ * info["TimeLimit.truncated"]), clear when it ended on a bounds violation (AuvEnv, verySimpleAuv.py:335-342). */
 int mvrl_step(mvrl_handle* h, const float* actions, float* obs, float* reward, uint8_t* done);
 int mvrl_step_async(mvrl_handle* h, const float* actions);
 int mvrl_step_wait(mvrl_handle* h, float* obs, float* reward, uint8_t* done);

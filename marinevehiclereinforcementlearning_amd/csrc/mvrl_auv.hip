@@ -79,7 +79,8 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
 
     istep += 1;                                  // verySimpleAuv.py:266
     const float time = (float)istep * io.dt;     // :267
-    bool done = istep >= io.max_steps;           // :270-272
+    const bool time_up = istep >= io.max_steps;  // :270-272
+    bool done = time_up;
     const int slot = (istep - 1) % 10;           // recentActions.appendleft (:275) as a ring
     const int nh = istep < 10 ? istep : 10;
 #pragma unroll
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     const float t2 = expf(-0.6f * rms);
     const float t3 = -0.1f * (a0 * a0 + a1 * a1 + a2 * a2) * (1.0f / 3.0f);
     io.reward[i] = (((t0 + t1) + t2) + t3) + bonus;
-    io.done[i] = done ? 1 : 0;
+    io.done[i] = done ? (time_up ? 3 : 1) : 0;  // bit 0 = done, bit 1 = time limit (else: bounds exceeded)
     if (io.aux) {  // timeHistory: Fx Fy N u_current v_current rmsAc r0..r4 (:389-403)
         float* ax = io.aux + (size_t)i * 11;
         ax[0] = Fg0; ax[1] = Fg1; ax[2] = Fh2; ax[3] = cur.x; ax[4] = cur.y; ax[5] = rms;

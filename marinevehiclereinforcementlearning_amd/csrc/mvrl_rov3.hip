@@ -222,7 +222,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_step_kernel(const Rov3Dev* __
         for (int q = 0; q < 4; q++) ax[3 + q] = fsign(cvr[q]) * sqrtf(fabsf(cvr[q]) * p->inv_thrust_k) * 60.f;
     }
     io.reward[i] = 0.f;
-    io.done[i] = done ? 1 : 0;
+    io.done[i] = done ? 3 : 0;  // bit 0 = done, bit 1 = time limit
     if (done && io.auto_reset) {
         if (io.term_obs) {
 #pragma unroll

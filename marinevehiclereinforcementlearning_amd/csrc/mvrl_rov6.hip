@@ -428,7 +428,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_step_kernel(const Rov6Dev* __
         for (int q = 0; q < 8; q++) ax[6 + q] = force_to_rpm(p, cvr[q]);
     }
     io.reward[i] = 0.f;  // 6DoF.py:575
-    io.done[i] = done ? 1 : 0;
+    io.done[i] = done ? 3 : 0;  // bit 0 = done, bit 1 = time limit (TimeLimit.truncated)
 
     if (done && io.auto_reset) {
         // SB3 VecEnv semantics: keep the terminal observation, hand back the first observation of a new episode
