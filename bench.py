@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Benchmark of the environment hot path: synthetic random-action roll-outs of the fused HIP step kernel.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|auv] [--gather root|all|none]
+
+One "step" = one env step of every environment of the batch = one launch of the fused step kernel per GPU
+(plus, for N > 1, the RCCL gather of observations/rewards/dones to rank 0 that BASELINE.json's 8-GPU config
+names).  Workloads (BASELINE.json configs):
+    c4 (default)  6-DoF + turbulence current, 1 048 576 envs per GPU   (configs[3]; x8 GPUs = configs[4])
+    c3            6-DoF, 262 144 envs                                    (configs[2])
+    c2            3-DoF, 65 536 envs                                     (configs[1])
+    auv           AuvEnv (Euler + turbulence + reward), 1 048 576 envs
+Inputs are resident in HBM before the timed region: a ring of pre-generated uniform(-1,1) action batches
+(counter-based RNG, seed 12345), random initial paths/attitudes, auto-reset every 250 steps, dt = 0.2 s,
+n_substeps = 4, control mode FAITHFUL.  Rank 0 prints ONE JSON line.
+
+For N > 1 the driver starts this file under torch.distributed.run (one rank per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# algorithmic bytes per env step (stated again in DESIGN.md)
+WORKLOADS = {
+    "c4": dict(model="rov6", n=1048576, flow=True, bytes=365, name="6-DoF + turbulence, 1 048 576 envs per GPU (BASELINE configs[3]; x8 = configs[4])"),
+    "c3": dict(model="rov6", n=262144, flow=False, bytes=297, name="6-DoF, 262 144 envs (BASELINE configs[2])"),
+    "c2": dict(model="rov3", n=65536, flow=False, bytes=165, name="3-DoF, 65 536 envs (BASELINE configs[1])"),
+    "auv": dict(model="auv", n=1048576, flow=True, bytes=389, name="AuvEnv + turbulence, 1 048 576 envs"),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+RING = 8
+
+
+def cpu_baseline(wl, flow_np, seed):
+    """The oracle (CPU restatement of the reference algorithm, fp64, OpenMP over envs) timed on this box's host
+    cores on a bounded sample of the same workload.  kind = "port"."""
+    from oracle import oracle as orc
+    from marinevehiclereinforcementlearning_amd import params as P
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    n = 65536 if wl["model"] != "auv" else 262144
+    rng = np.random.default_rng(seed)
+    ft = None
+    if flow_np is not None:
+        ft = orc.FlowTable(flow_np["table"], flow_np["dt"], flow_np["dx"], flow_np["dy"])
+    if wl["model"] == "auv":
+        env = orc.OracleAuvEnv(n, "f64", flow=ft)
+        init = np.concatenate([(rng.random((n, 2)) - 0.5), rng.random((n, 2)) * 2 * np.pi,
+                               rng.random((n, 1)) * 5.0, np.ones((n, 11))], axis=1)
+        env.reset(init)
+        act = rng.uniform(-1, 1, size=(n, 3))
+    else:
+        dof = 6 if wl["model"] == "rov6" else 3
+        env = orc.OracleRovEnv(dof, n, "f64", n_substeps=4, max_steps=10 ** 9, flow=ft)
+        npos = 3 if dof == 6 else 2
+        init = np.concatenate([(rng.random((n, 2 * npos)) - 0.5) * 10, rng.random((n, dof - npos)) * 2 * np.pi], axis=1)
+        env.reset(init, toffset=rng.random(n) * 5.0 if ft is not None else None)
+        act = rng.uniform(-1, 1, size=(n, dof))
+    t0 = time.perf_counter()
+    env.step(act)
+    one = time.perf_counter() - t0
+    steps = int(max(3, min(400, 12.0 / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        env.step(act)
+    el = time.perf_counter() - t0
+    return {"value": n * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} envs x {steps} steps of the same workload, fp64 C oracle with OpenMP over envs ({el:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--gather", default="root", choices=["root", "all", "none"])
+    ap.add_argument("--n-substeps", type=int, default=4)
+    ap.add_argument("--control-mode", default="faithful", choices=["faithful", "zoh"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=12345)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from marinevehiclereinforcementlearning_amd import build, distributed as D
+    from marinevehiclereinforcementlearning_amd.flow import ReconstructedFlow
+    from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} must be launched as: python -m torch.distributed.run --nnodes=1 "
+                 f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
+    rank, world, local_rank = D.init_from_env("nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if not os.path.exists(os.path.join(REPO, "marinevehiclereinforcementlearning_amd", "libmvrl.so")):
+        if rank == 0:
+            build.build_lib()
+        if world > 1:
+            dist.barrier()
+
+    wl = dict(WORKLOADS[args.workload])
+    n = args.envs_per_gpu or wl["n"]
+    K, W = args.steps, args.warmup
+
+    # ---- synthetic turbulence table (2000 snapshots of the shipped 41 x 61 grid, AuvEnv scaling) ----------
+    flow, flow_np = None, None
+    if wl["flow"]:
+        flow = ReconstructedFlow.synthetic(n_modes=8, n_time=2000, device=local_rank)
+        flow.scale(11., 1., 2., translate=(-1.65, -1.1))
+        if rank == 0 and not args.no_cpu_baseline and world == 1:
+            flow_np = dict(table=flow.table_uv().astype(np.float64), dt=flow.dt, dx=flow.dx, dy=flow.dy)
+
+    env = MarineVecEnv(wl["model"], n, seed=args.seed, n_substeps=args.n_substeps, control_mode=args.control_mode,
+                       flow=flow, device=local_rank, env_offset=rank * n, infos="lean")
+    act_dim, obs_dim = env.action_space.shape[0], env.observation_space.shape[0]
+    h = env.handle
+    stream = torch.cuda.current_stream().cuda_stream
+    ring = torch.empty((RING, n, act_dim), dtype=torch.float32, device=dev)
+    for r in range(RING):
+        h.fill_uniform_dev(ring[r].data_ptr(), n * act_dim, args.seed, rank * RING + r, -1.0, 1.0, stream)
+    env.reset_tensors()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def run_plain(steps):
+        for k in range(steps):
+            env.step_tensors(ring[k % RING])
+
+    # ---- N > 1: gather overlapped with the next step on a side stream, outputs double-buffered ---------------
+    gather = None
+    if world > 1 and args.gather != "none":
+        gather = [D.OutputGather(world * n, obs_dim, dev, mode=args.gather) for _ in range(2)]
+        side = torch.cuda.Stream(device=dev)
+        ev_step = [torch.cuda.Event() for _ in range(2)]
+        ev_gather = [torch.cuda.Event() for _ in range(2)]
+
+    def run_gather(steps):
+        main = torch.cuda.current_stream()
+        for k in range(steps):
+            b = k & 1
+            if k >= 2:
+                main.wait_event(ev_gather[b])          # buffer b is free again once gather k-2 has finished
+            obs, rew, done = env.step_tensors(ring[k % RING])
+            gather[b].pack(obs, rew, done)             # packs into this buffer's send tensor on the main stream
+            ev_step[b].record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_step[b])
+                gather[b].exchange()
+                ev_gather[b].record(side)
+        main.wait_stream(side)
+
+    # ---- warm-up, then the timed region: EXACTLY K steps between barrier+synchronize pairs --------------------
+    run = run_gather if gather is not None else run_plain
+    run(W)
+    sync()
+    if gather is None:
+        h.timing_begin(stream)
+    t0 = time.perf_counter()
+    run(K)
+    if gather is None:
+        kern_ms, launches = h.timing_end(stream)
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    extra = {}
+    if gather is not None:
+        # the same K steps without the collective: kernel-only rate (what a policy sharded the same way would see)
+        # and the HIP-event timing of the dominant kernel for the roofline entry
+        sync()
+        h.timing_begin(stream)
+        t1 = time.perf_counter()
+        run_plain(K)
+        kern_ms, launches = h.timing_end(stream)
+        sync()
+        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+        extra["value_no_gather"] = world * n * K / float(e2.item())
+        extra["gather"] = {"mode": args.gather, "bytes_per_step_at_root": gather[0].bytes_per_step(),
+                           "overlapped_with_next_step": True}
+
+    obs_t, _, _ = env._ensure_tensors()
+    finite = bool(torch.isfinite(obs_t).all().item())
+
+    if rank == 0:
+        value = world * n * K / elapsed
+        per_launch_s = kern_ms * 1e-3 / max(1, launches)
+        achieved = wl["bytes"] * n / per_launch_s / 1e9
+        traffic = None
+        tp = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch") if n == wl["n"] else None
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (whole node) + achieved HBM GB/s, 6-DoF batch", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "envs_per_gpu": n, "global_envs": world * n, "dt": 0.2 if wl["model"] != "auv" else 0.02,
+                       "n_substeps": args.n_substeps, "control_mode": args.control_mode, "episode_len": 250,
+                       "kernel": env.variant, "actions": f"ring of {RING} pre-generated uniform(-1,1) batches in HBM"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_us_per_launch": per_launch_s * 1e6, "algorithmic_bytes_per_env_step": wl["bytes"],
+                         "note": "VALU-bound kernel (~7 k lane-ops per env step); HBM fraction reported as the contract asks"},
+            "outputs_finite": finite,
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl, flow_np, args.seed)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""Sharding of one environment batch over the GPUs of a node: one process per GPU (torch.distributed; backend
+"nccl" is RCCL on ROCm, "gloo" on CPU for tests), contiguous shards, and ONE collective per env step - the gather
+of (observation, reward, done) rows to rank 0 over xGMI, which replaces the pipe recv + np.stack of SB3's
+SubprocVecEnv (main_00_sbl.py:145).
+
+The environments are independent, so stepping needs no communication; RNG streams are keyed by the GLOBAL env
+index (mvrl_config.env_offset), which makes N envs on one GPU identical to the concatenation of the shards.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_global, rank, world_size):
+    """Contiguous block partition; the first (n_global % world_size) ranks own one extra env."""
+    base, extra = divmod(int(n_global), int(world_size))
+    count = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return offset, count
+
+
+def init_from_env(backend=None):
+    """Join the process group torchrun set up (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+class OutputGather:
+    """Per-step gather of the shards' (obs, reward, done) to `root`.
+
+    Rows are padded to the largest shard so that every rank sends the same shape (a requirement of
+    dist.gather); root returns views trimmed and concatenated in global env order.  `mode="all"` all-gathers
+    instead (every rank ends up with the full batch - for a replicated policy)."""
+
+    def __init__(self, n_global, obs_dim, device, root=0, mode="root", group=None):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.root, self.mode, self.group = root, mode, group
+        self.n_global, self.obs_dim = int(n_global), int(obs_dim)
+        self.ranges = [shard_range(n_global, r, self.world) for r in range(self.world)]
+        self.cmax = max(c for _, c in self.ranges)
+        self.device = device
+        self.row = obs_dim + 2  # obs | reward | done (as f32: one message instead of three)
+        self.send = torch.zeros((self.cmax, self.row), dtype=torch.float32, device=device)
+        need_recv = (mode == "all") or (self.rank == root)
+        self.recv = torch.zeros((self.world, self.cmax, self.row), dtype=torch.float32, device=device) if need_recv else None
+        self.even = all(c == self.cmax for _, c in self.ranges)
+
+    def bytes_per_step(self):
+        return self.world * self.cmax * self.row * 4
+
+    def pack(self, obs, reward, done):
+        c = obs.shape[0]
+        self.send[:c, : self.obs_dim].copy_(obs)
+        self.send[:c, self.obs_dim].copy_(reward)
+        self.send[:c, self.obs_dim + 1].copy_(done)
+        return self.send
+
+    def exchange(self):
+        if self.world == 1:
+            if self.recv is not None:
+                self.recv[0].copy_(self.send)
+            return
+        if self.mode == "all":
+            dist.all_gather_into_tensor(self.recv.view(-1, self.row), self.send, group=self.group)
+        else:
+            if self.rank == self.root:
+                dist.gather(self.send, gather_list=list(self.recv.unbind(0)), dst=self.root, group=self.group)
+            else:
+                dist.gather(self.send, gather_list=None, dst=self.root, group=self.group)
+
+    def unpack(self):
+        """On root (or everywhere in mode "all"): (obs[N, obs_dim], reward[N], done[N] u8) in global env order."""
+        if self.recv is None:
+            return None
+        if self.even:
+            flat = self.recv.view(-1, self.row)
+        else:
+            flat = torch.cat([self.recv[r, :c] for r, (_, c) in enumerate(self.ranges)], dim=0)
+        return flat[:, : self.obs_dim], flat[:, self.obs_dim], flat[:, self.obs_dim + 1].to(torch.uint8)
+
+    def __call__(self, obs, reward, done):
+        self.pack(obs, reward, done)
+        self.exchange()
+        return self.unpack()
+
+
+class ShardedVecEnv:
+    """A global batch of `n_global` envs split over the ranks of the process group.
+
+    `make_shard(offset, count, rank)` builds this rank's stepper: any object with `reset_tensors()` and
+    `step_tensors(actions) -> (obs, reward, done)` returning torch tensors on `device` (MarineVecEnv on a GPU;
+    tests inject a CPU stepper).  `step(actions_local)` steps the local shard and gathers the outputs."""
+
+    def __init__(self, make_shard, n_global, obs_dim, device, gather="root", group=None):
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.offset, self.count = shard_range(n_global, self.rank, self.world)
+        self.local = make_shard(self.offset, self.count, self.rank)
+        self.gather = None if gather in (None, "none") else OutputGather(n_global, obs_dim, device, mode=gather, group=group)
+
+    def reset(self):
+        obs = self.local.reset_tensors()
+        if self.gather is None:
+            return obs
+        z = torch.zeros(obs.shape[0], dtype=torch.float32, device=obs.device)
+        out = self.gather(obs, z, z)
+        return None if out is None else out[0]
+
+    def step(self, actions_local):
+        obs, rew, done = self.local.step_tensors(actions_local)
+        if self.gather is None:
+            return obs, rew, done
+        return self.gather(obs, rew, done)

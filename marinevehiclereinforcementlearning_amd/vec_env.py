@@ -1,0 +1,198 @@
+"""Vectorised environment with the stable-baselines3 `VecEnv` calling convention, backed by libmvrl.so.
+
+Replaces `SubprocVecEnv([make_env(i, env_kwargs) for i in range(nProc)])` of the reference's training
+drivers (tag_00_Dec2023_simpleControlTurbulence/main_00_sbl.py:145-146): instead of one Python process per
+environment talking over pipes, all N environments are lanes of one HIP kernel launch on one GPU.
+
+SB3 is not a dependency (it is not installed in the build image): the class duck-types the VecEnv interface
+of SB3 1.6-1.8 (gym 0.21 API, which is what the reference uses):
+    num_envs, observation_space, action_space
+    reset() -> obs[N, obs_dim] f32
+    step_async(actions) ; step_wait() -> (obs, rewards[N] f32, dones[N] bool, infos: list[dict])
+    step(actions) ; close() ; seed() ; get_attr / set_attr / env_method / env_is_wrapped ; render()
+with SB3's auto-reset semantics: on a `done` the returned row of `obs` is the first observation of the next
+episode, the last observation of the finished one is in infos[i]["terminal_observation"], and
+infos[i]["TimeLimit.truncated"] tells whether the episode ended on the time limit
+(read at main_02_sbl_contrib_customBuffer.py:154).
+
+`infos="lean"` returns one shared, lazily-evaluated infos object instead of N dicts - at 1e5..1e7 environments the
+list of dicts alone costs more than the physics.  `step_tensors` keeps actions/observations on the GPU
+(torch tensors, zero-copy through raw device pointers).
+"""
+import numpy as np
+
+from . import _lib, params as P
+from .spaces import unit_box
+
+
+class _LeanInfos:
+    """Sequence-like infos for huge batches: infos[i] builds the dict on demand."""
+
+    def __init__(self, env, done_bits, term_obs_fetch):
+        self._env, self._bits, self._fetch = env, done_bits, term_obs_fetch
+        self._term = None
+
+    def __len__(self):
+        return len(self._bits)
+
+    def __getitem__(self, i):
+        b = int(self._bits[i])
+        if not b:
+            return {}
+        if self._term is None:
+            self._term = self._fetch()
+        return {"terminal_observation": self._term[i], "TimeLimit.truncated": bool(b & 2)}
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    @property
+    def done_indices(self):
+        return np.nonzero(self._bits)[0]
+
+
+class MarineVecEnv:
+    """N BlueROV2 / AUV environments on one GPU.
+
+    model: "rov6" | "rov3" | "auv".  Remaining keyword arguments mirror the reference constructors
+    (`dt`, `maxSteps` - 6DoF.py:446 / 3DoF.py:376; `noiseMagCoeffs`, `noiseMagActuation`, `currentVelScale`,
+    `currentTurbScale`, `stopOnBoundsExceeded` - verySimpleAuv.py:77-78) plus the integrator settings that are
+    this build's (`n_substeps`, `control_mode`).
+    """
+
+    metadata = {"render.modes": []}
+
+    def __init__(self, model, num_envs, *, seed=0, dt=None, maxSteps=250, n_substeps=4, control_mode="faithful",
+                 fixed_setpoint=False, flow=None, currentVelScale=1.0, currentTurbScale=2.0, noiseMagCoeffs=0.0,
+                 noiseMagActuation=0.0, stopOnBoundsExceeded=True, device=0, env_offset=0, infos="dict",
+                 vehicle_params=None):
+        self.model = P.MODEL_NAMES[model] if isinstance(model, str) else int(model)
+        self.model_name = {v: k for k, v in P.MODEL_NAMES.items()}[self.model]
+        self.num_envs = int(num_envs)
+        act, obs, init, words, aux = P.MODEL_DIMS[self.model]
+        self.action_space = unit_box(act)
+        self.observation_space = unit_box(obs)
+        self.infos_mode = infos
+        cm = {"faithful": P.CTRL_FAITHFUL, "zoh": P.CTRL_ZOH}[control_mode] if isinstance(control_mode, str) else control_mode
+        use_flow = flow is not None
+        if self.model == P.MODEL_AUV and flow is None:
+            raise ValueError("AuvEnv needs a turbulence field (flow=ReconstructedFlow(...)): verySimpleAuv.py:102-104")
+        kw = {}
+        if self.model == P.MODEL_AUV:
+            kw["auv"] = P.auv_params(noiseMagCoeffs, noiseMagActuation, stopOnBoundsExceeded)
+        elif vehicle_params is not None:
+            kw["rov6" if self.model == P.MODEL_ROV6 else "rov3"] = vehicle_params
+        self.cfg = P.make_config(self.model, self.num_envs, dt=dt, n_substeps=n_substeps, max_steps=maxSteps,
+                                 control_mode=cm, fixed_setpoint=fixed_setpoint, auto_reset=True, seed=seed or 0,
+                                 use_flow=use_flow, device=device, env_offset=env_offset, **kw)
+        self.dt = self.cfg.dt
+        self._h = _lib.Handle(self.cfg)
+        self.flow = flow
+        if use_flow:
+            if self.model == P.MODEL_AUV:
+                flow.scale(11., currentVelScale, currentTurbScale, translate=(-1.65, -1.1))  # verySimpleAuv.py:104
+            self._h.set_flow(flow.table_uv(), flow.dt, flow.dx, flow.dy)
+        self._pending = False
+        self._tensors = None
+
+    # ---- VecEnv API -----------------------------------------------------------------------------
+    def reset(self, init=None):
+        """All environments start a new episode.  `init` [N, init_dim] gives explicit initial values (see
+        include/mvrl.h); otherwise they are drawn on the device (counter-based RNG keyed by seed and env id)."""
+        return self._h.reset(init=init).copy()
+
+    def step_async(self, actions):
+        self._h.step_async(actions)  # not clipped here: the reference envs apply the raw action (6DoF.py:545-551)
+        self._pending = True
+
+    def step_wait(self):
+        obs, rew, done = self._h.step_wait()
+        self._pending = False
+        bits = done.copy()
+        dones = bits != 0
+        if self.infos_mode == "lean":
+            infos = _LeanInfos(self, bits, self._h.terminal_obs)
+        else:
+            infos = [{} for _ in range(self.num_envs)]
+            idx = np.nonzero(dones)[0]
+            if len(idx):
+                term = self._h.terminal_obs()
+                for i in idx:
+                    infos[i] = {"terminal_observation": term[i].copy(), "TimeLimit.truncated": bool(bits[i] & 2)}
+        return obs.copy(), rew.copy(), dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        if self._h is not None:
+            self._h.close()
+            self._h = None
+
+    def seed(self, seed=None):
+        return [seed] * self.num_envs
+
+    def render(self, mode="human"):
+        return None
+
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self, attr_name)] * n
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self, method_name)(*method_args, **method_kwargs)] * n
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [False] * n
+
+    @property
+    def unwrapped(self):
+        return self
+
+    # ---- extras -----------------------------------------------------------------------------------
+    @property
+    def variant(self):
+        return self._h.variant
+
+    @property
+    def handle(self):
+        return self._h
+
+    def get_state(self):
+        return self._h.get_state()
+
+    def set_state(self, st):
+        self._h.set_state(st)
+
+    def _ensure_tensors(self):
+        if self._tensors is None:
+            import torch
+            dev = torch.device("cuda", self.cfg.device)
+            n = self.num_envs
+            self._tensors = (torch.empty((n, self.observation_space.shape[0]), dtype=torch.float32, device=dev),
+                             torch.empty((n,), dtype=torch.float32, device=dev),
+                             torch.empty((n,), dtype=torch.uint8, device=dev))
+        return self._tensors
+
+    def reset_tensors(self):
+        import torch
+        obs, _, _ = self._ensure_tensors()
+        self._h.reset_dev(None, None, obs.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return obs
+
+    def step_tensors(self, actions):
+        """Device-resident step: `actions` is a contiguous float32 CUDA(HIP) tensor [N, act_dim]; returns
+        (obs, reward, done_bits) tensors that are overwritten by the next call.  Enqueued on torch's current stream;
+        nothing crosses PCIe."""
+        import torch
+        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
+        obs, rew, done = self._ensure_tensors()
+        self._h.step_dev(actions.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream)
+        return obs, rew, done
