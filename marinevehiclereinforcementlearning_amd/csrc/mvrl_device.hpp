@@ -9,6 +9,13 @@
 #include <type_traits>
 
 #define MVRL_BLOCK 256
+// Launch bounds of the rigid-body step kernels.  The second argument (min waves per SIMD) caps the register
+// budget; tuned on hardware (see DESIGN.md "occupancy").
+#ifdef MVRL_MIN_WAVES
+#define MVRL_STEP_BOUNDS __launch_bounds__(MVRL_BLOCK, MVRL_MIN_WAVES)
+#else
+#define MVRL_STEP_BOUNDS __launch_bounds__(MVRL_BLOCK)
+#endif
 
 namespace mvrl {
 
@@ -32,17 +39,30 @@ __device__ __forceinline__ float mod_two_pi(float x) {
     return r;
 }
 
-// resources.angleError (resources.py:75-95): signed difference in [-pi, pi)
+// resources.angleError (resources.py:75-95): signed difference in [-pi, pi).  The reference takes the smaller of
+// (d mod 2pi) and -((-d) mod 2pi); that is d minus the nearest multiple of 2pi, with the tie d = pi (mod 2pi)
+// resolved to -pi.
 __device__ __forceinline__ float angle_error(float psi_d, float psi) {
-    float d = psi_d - psi;
-    float a = mod_two_pi(d);
-    float b = mod_two_pi(-d);
-    return (a < b) ? a : -b;
+    const float d = psi_d - psi;
+    const float q = rintf(d * MVRL_INV_TWO_PI);
+    float r = fmaf(-q, MVRL_TWO_PI_HI, d);
+    r = fmaf(-q, MVRL_TWO_PI_LO, r);
+    r = (r >= 3.14159265f) ? r - MVRL_TWO_PI_HI : r;
+    r = (r < -3.14159265f) ? r + MVRL_TWO_PI_HI : r;
+    return r;
 }
 
 // sin & cos with ~1 ulp accuracy for |x| up to a few thousand radians, branch-free (Cody-Waite reduction by
 // pi/2 in three exact-product pieces + Cephes-style minimax polynomials on [-pi/4, pi/4]).
 __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
+#ifdef MVRL_NATIVE_TRIG
+    // hardware v_sin_f32 / v_cos_f32 (argument in revolutions): ~4x fewer issue slots, ~1e-6 absolute accuracy
+    const float rev = x * MVRL_INV_TWO_PI;
+    const float fr = rev - floorf(rev);
+    s = __builtin_amdgcn_sinf(fr);
+    c = __builtin_amdgcn_cosf(fr);
+    return;
+#endif
     float q = rintf(x * 0.63661977f);
     float r = fmaf(-q, 1.5703125f, x);
     r = fmaf(-q, 4.837512969970703125e-4f, r);

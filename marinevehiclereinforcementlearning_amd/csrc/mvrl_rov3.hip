@@ -17,8 +17,7 @@ struct Pid3 {
 // stage slopes, not from the rounded fp32 states.
 template <bool HAS_DT, bool USE_INC, class PP>
 __device__ __forceinline__ void control3(PP p, const float* y, const float* sp, Pid3& s, float dtp, float inv_den,
-                                         const float* dpose, float c, float sn, float* F, float* gcf, float* cv_raw,
-                                         bool keep) {
+                                         const float* dpose, bool inc_valid, float c, float sn, float* F, float* aux_row) {
     p = launder(p);
     float e[3] = {sp[0] - y[0], sp[1] - y[1], angle_error(sp[2], y[2])};
     float u[3];
@@ -27,7 +26,8 @@ __device__ __forceinline__ void control3(PP p, const float* y, const float* sp, 
         float de = e[i] - s.eold[i];
         if (USE_INC) {
             const float di = -dpose[i];
-            de = (fabsf(de - di) <= 1e-5f) ? di : de;
+            const bool use = (i < 2) ? inc_valid : (inc_valid && fabsf(de - di) <= 1e-5f);
+            de = use ? di : de;
         }
         float dedt = de * inv_den;
         if (HAS_DT) s.eint[i] = fmaf(0.5f * (s.eold[i] + e[i]), dtp, s.eint[i]);
@@ -37,13 +37,13 @@ __device__ __forceinline__ void control3(PP p, const float* y, const float* sp, 
         s.eold[i] = e[i];
     }
     float Xd = u[0] * c + u[1] * sn, Yd = -u[0] * sn + u[1] * c, Nd = u[2];
-    if (keep) { gcf[0] = Xd; gcf[1] = Yd; gcf[2] = Nd; }
+    if (aux_row) { aux_row[0] = Xd; aux_row[1] = Yd; aux_row[2] = Nd; }  // timeHistory F0..F2 (3DoF.py:498-507)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         float cv = fmaf(p->Ainv[3 * i + 2], Nd, fmaf(p->Ainv[3 * i + 1], Yd, p->Ainv[3 * i] * Xd));
         float f = clampf(cv, -p->f_max, p->f_max);   // rpm clamp +-3500 and dead-band 300 in force space (3DoF.py:171-180)
         F[i] = (fabsf(f) < p->f_dead) ? 0.f : f;
-        if (keep) cv_raw[i] = cv;
+        if (aux_row) aux_row[3 + i] = fsign(cv) * sqrtf(fabsf(cv) * p->inv_thrust_k) * 60.f;  // u0..u3 [rpm]
     }
 }
 
@@ -96,11 +96,11 @@ __device__ __forceinline__ void dynamics3(PP p, const float* y, float c, float s
 
 template <bool FLOW, bool HAS_DT, class PP>
 __device__ __forceinline__ void derivs3(PP p, const float* y, const float* sp, Pid3& pid, float dtp, float inv_den,
-                                        const float* dpose, float2 cur, float* dy, float* gcf, float* cv_raw, bool keep) {
+                                        const float* dpose, bool inc_valid, float2 cur, float* dy, float* aux_row) {
     float sn, c;
     sincos_f32(y[2], sn, c);
     float F[4];
-    control3<HAS_DT, true>(p, y, sp, pid, dtp, inv_den, dpose, c, sn, F, gcf, cv_raw, keep);
+    control3<HAS_DT, true>(p, y, sp, pid, dtp, inv_den, dpose, inc_valid, c, sn, F, aux_row);
     dynamics3<FLOW>(p, y, c, sn, F, cur, dy);
 }
 
@@ -129,27 +129,26 @@ __device__ __forceinline__ void random_init3(uint64_t seed, int64_t gid, uint32_
 enum { R3_Y = 0, R3_EOLD = 6, R3_EINT = 9, R3_SP = 12, R3_PATH = 15, R3_TOFF = 19, R3_ISTEP = 20, R3_WORDS = 21 };
 
 template <class PP, bool ZOH, bool FLOW>
-__global__ __launch_bounds__(MVRL_BLOCK) void rov3_step_kernel(const Rov3Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
+__global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
-    const uint32_t i = blockIdx.x * MVRL_BLOCK + threadIdx.x;
-    if (i >= (uint32_t)io.n) return;
+    const uint32_t i_in = blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i_in >= (uint32_t)io.n) return;
     const uint32_t n32 = (uint32_t)io.n;  // see mvrl_rov6.hip: 32-bit byte offsets -> saddr addressing
     char* const stb = reinterpret_cast<char*>(io.state);
-#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) << 2)))
+#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) << 2)))
+#define LANE i_in
     float y[6], sp[3], path[4];
     Pid3 pid;
 #pragma unroll
     for (int k = 0; k < 6; k++) y[k] = ST(R3_Y + k);
 #pragma unroll
     for (int k = 0; k < 3; k++) { pid.eold[k] = ST(R3_EOLD + k); pid.eint[k] = ST(R3_EINT + k); }
-#pragma unroll
-    for (int k = 0; k < 4; k++) path[k] = ST(R3_PATH + k);
     int istep = __float_as_int(ST(R3_ISTEP));
     if (io.fixed_sp) {
 #pragma unroll
         for (int k = 0; k < 3; k++) sp[k] = ST(R3_SP + k);
     } else {  // 3DoF.py:469-472
-        const float* a = io.actions + (size_t)i * 3;
+        const float* a = io.actions + (size_t)i_in * 3;
         sp[0] = fmaf(a[0], p->act_scale[0], y[0]);
         sp[1] = fmaf(a[1], p->act_scale[1], y[1]);
         sp[2] = fmaf(a[2], p->act_scale[2], y[2]);
@@ -161,17 +160,16 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_step_kernel(const Rov3Dev* __
     if (first) { pid.eold[0] = sp[0] - y[0]; pid.eold[1] = sp[1] - y[1]; pid.eold[2] = angle_error(sp[2], y[2]); }
 
     const float h = io.dt / (float)io.n_sub, hh = 0.5f * h, h6 = h / 6.f, inv_hh = 1.0f / hh;
-    float gcf[3] = {0, 0, 0}, cvr[4] = {0, 0, 0, 0};
-    const bool want_aux = (io.aux != nullptr);
-    float inc_prev[3] = {1e30f, 1e30f, 1e30f};  // see mvrl_rov6.hip
+    float* const aux_row = io.aux ? io.aux + (size_t)i_in * 7 : nullptr;
+    float inc_prev[3] = {0.f, 0.f, 0.f};  // see mvrl_rov6.hip
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[6], acc[6], yt[6];
-        const bool last = want_aux && (ks == io.n_sub - 1);
+        float* const aux_last = (ks == io.n_sub - 1) ? aux_row : nullptr;
         if (ZOH) {
             float sn, c, F[4];
             sincos_f32(y[2], sn, c);
-            if (first && ks == 0) control3<false, false>(p, y, sp, pid, 0.f, 1e9f, nullptr, c, sn, F, gcf, cvr, true);
-            else control3<true, false>(p, y, sp, pid, h, 1.0f / h, nullptr, c, sn, F, gcf, cvr, true);
+            if (first && ks == 0) control3<false, false>(p, y, sp, pid, 0.f, 1e9f, nullptr, false, c, sn, F, aux_last);
+            else control3<true, true>(p, y, sp, pid, h, 1.0f / h, inc_prev, ks > 0, c, sn, F, aux_last);
             dynamics3<FLOW>(p, y, c, sn, F, cur, k);
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
@@ -185,26 +183,28 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_step_kernel(const Rov3Dev* __
             for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
             sincos_f32(yt[2], sn, c);
             dynamics3<FLOW>(p, yt, c, sn, F, cur, k);
+#pragma unroll
+            for (int q = 0; q < 3; q++) inc_prev[q] = h6 * (acc[q] + k[q]);
         } else {
             float dp[3], d2[3], d3[3];
 #pragma unroll
             for (int q = 0; q < 3; q++) dp[q] = inc_prev[q];
-            derivs3<FLOW, false>(p, y, sp, pid, 0.f, 1e9f, dp, cur, k, gcf, cvr, false);
+            derivs3<FLOW, false>(p, y, sp, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr);
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
 #pragma unroll
             for (int q = 0; q < 3; q++) dp[q] = hh * k[q];
-            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, dp, cur, k, gcf, cvr, false);
+            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, dp, true, cur, k, nullptr);
 #pragma unroll
             for (int q = 0; q < 3; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
-            derivs3<FLOW, false>(p, yt, sp, pid, 0.f, 1e9f, dp, cur, k, gcf, cvr, false);
+            derivs3<FLOW, false>(p, yt, sp, pid, 0.f, 1e9f, dp, true, cur, k, nullptr);
 #pragma unroll
             for (int q = 0; q < 3; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
-            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, dp, cur, k, gcf, cvr, last);
+            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, dp, true, cur, k, aux_last);
 #pragma unroll
             for (int q = 0; q < 3; q++) inc_prev[q] = h6 * (acc[q] + k[q]) - d3[q];
         }
@@ -212,15 +212,18 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_step_kernel(const Rov3Dev* __
         for (int q = 0; q < 6; q++) y[q] = fmaf(h6, acc[q] + k[q], y[q]);
     }
     y[2] = mod_two_pi(y[2]);  // 3DoF.py:480
+    // The epilogue addresses the same SoA planes as the prologue.  Left alone, LLVM keeps all ~40 prologue
+    // addresses alive in VGPR pairs across the whole RK4 loop (~75 registers, the difference between 2 and 3 waves
+    // per SIMD) instead of recomputing them; hiding the lane index behind an empty asm makes it recompute.
+    uint32_t i = i_in;
+    asm volatile("" : "+v"(i));
+#undef LANE
+#define LANE i
+#pragma unroll
+    for (int k = 0; k < 4; k++) path[k] = ST(R3_PATH + k);
     float o[5];
     observe3(p, y, path, sp, o);
     const bool done = istep >= io.max_steps;
-    if (want_aux) {  // timeHistory F0..F2, u0..u3 (3DoF.py:498-507)
-        float* ax = io.aux + (size_t)i * 7;
-        ax[0] = gcf[0]; ax[1] = gcf[1]; ax[2] = gcf[2];
-#pragma unroll
-        for (int q = 0; q < 4; q++) ax[3 + q] = fsign(cvr[q]) * sqrtf(fabsf(cvr[q]) * p->inv_thrust_k) * 60.f;
-    }
     io.reward[i] = 0.f;
     io.done[i] = done ? 3 : 0;  // bit 0 = done, bit 1 = time limit
     if (done && io.auto_reset) {
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_step_kernel(const Rov3Dev* __
     }
     ST(R3_ISTEP) = __int_as_float(istep);
 #undef ST
+#undef LANE
 }
 
 __global__ __launch_bounds__(MVRL_BLOCK) void rov3_reset_kernel(const Rov3Dev* __restrict__ pg, float* state, int64_t n, const uint8_t* mask,

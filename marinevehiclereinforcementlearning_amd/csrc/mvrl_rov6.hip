@@ -20,15 +20,20 @@ struct Pid6 {
     float eint[6];
 };
 
-// Body axes iHat/jHat/kHat of updateMovingCoordSystem (6DoF.py:238-242): columns of Rx(phi)Ry(theta)Rz(psi).
+// Products of the six sines/cosines that both the body axes (updateMovingCoordSystem, 6DoF.py:238-242: columns of
+// Rx(phi)Ry(theta)Rz(psi)) and the kinematic transform J1 (resources.py:122-126) are made of.
 struct Axes {
-    float i0, i1, i2, j0, j1, j2, k0, k1, k2;
+    float i0, i1, i2, j0, j1, j2, k0, k1, k2;   // iHat, jHat, kHat
+    float pA, pB, pC, pE, pF, pG, pH;           // c(phi)s(psi), s(phi)s(theta)c(psi), s(phi)s(psi), c(phi)c(psi), s(phi)s(theta)s(psi), s(phi)c(psi), c(phi)s(theta)s(psi)
 };
 __device__ __forceinline__ Axes body_axes(const Trig6& t) {
     Axes a;
-    a.i0 = t.cth * t.cps;  a.i1 = t.cph * t.sps + t.sph * t.sth * t.cps;  a.i2 = t.sph * t.sps - t.cph * t.sth * t.cps;
-    a.j0 = -t.cth * t.sps; a.j1 = t.cph * t.cps - t.sph * t.sth * t.sps;  a.j2 = t.sph * t.cps + t.cph * t.sth * t.sps;
-    a.k0 = t.sth;          a.k1 = -t.sph * t.cth;                          a.k2 = t.cph * t.cth;
+    const float stcps = t.sth * t.cps, stsps = t.sth * t.sps;
+    a.pA = t.cph * t.sps; a.pB = t.sph * stcps; a.pC = t.sph * t.sps; const float pD = t.cph * stcps;
+    a.pE = t.cph * t.cps; a.pF = t.sph * stsps; a.pG = t.sph * t.cps; a.pH = t.cph * stsps;
+    a.i0 = t.cth * t.cps;  a.i1 = a.pA + a.pB;  a.i2 = a.pC - pD;
+    a.j0 = -t.cth * t.sps; a.j1 = a.pE - a.pF;  a.j2 = a.pG + a.pH;
+    a.k0 = t.sth;          a.k1 = -t.sph * t.cth; a.k2 = t.cph * t.cth;
     return a;
 }
 
@@ -44,7 +49,7 @@ __device__ __forceinline__ Axes body_axes(const Trig6& t) {
 // change, where the rounded difference is the right one).
 template <bool HAS_DT, bool USE_INC, class PP>
 __device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6& s, float dtp,
-                                     float inv_den, const float* dpose, float* u) {
+                                     float inv_den, const float* dpose, bool inc_valid, float* u) {
     p = launder(p);  // phase-local scalar loads of the constants (see mvrl_device.hpp)
     float e[6];
     e[0] = sp[0] - y[0]; e[1] = sp[1] - y[1]; e[2] = sp[2] - y[2];
@@ -54,8 +59,12 @@ __device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6
     for (int i = 0; i < 6; i++) {
         float de = e[i] - s.eold[i];
         if (USE_INC) {
+            // inc_valid is wave-uniform (false only for the first PID call of an env step, whose predecessor belongs to
+            // the previous step).  x, y, z, phi, theta errors are plain differences sp - pose, so -dpose is their
+            // change; the yaw error can change branch (wrap at +-pi), which the consistency test detects.
             const float di = -dpose[i];
-            de = (fabsf(de - di) <= 1e-5f) ? di : de;
+            const bool use = (i < 5) ? inc_valid : (inc_valid && fabsf(de - di) <= 1e-5f);
+            de = use ? di : de;
         }
         float dedt = de * inv_den;
         if (HAS_DT) s.eint[i] = fmaf(0.5f * (s.eold[i] + e[i]), dtp, s.eint[i]);
@@ -235,10 +244,11 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
     float cd = t.cth;
     cd = (fabsf(cd) < 1e-12f) ? 1e-6f : ((fabsf(cd) < 1e-6f) ? 1e-6f * fsign(cd) : cd);
     float icd = 1.0f / cd;
-    float cpsst = t.cps * t.sth, spsst = t.sps * t.sth;
-    dy[0] = t.cps * t.cth * u + (-t.sps * t.cph + cpsst * t.sph) * v + (t.sps * t.sph + cpsst * t.sph) * w;
-    dy[1] = t.sps * t.cth * u + (t.cps * t.cph + spsst * t.sph) * v + (-t.cps * t.sph + spsst * t.cph) * w;
-    dy[2] = -t.sth * u + t.cth * t.sph * v + t.cth * t.cph * w;
+    // J1 rows from the shared products: [0,1] = pB - pA, [0,2] = pC + pB (the reference's typo), [1,1] = pE + pF,
+    // [1,2] = pH - pG, [2,1] = c(theta)s(phi) = -k1, [2,2] = c(theta)c(phi) = k2; column 0 = iHat(0), -jHat(0), -s(theta)
+    dy[0] = ax.i0 * u + (ax.pB - ax.pA) * v + (ax.pC + ax.pB) * w;
+    dy[1] = -ax.j0 * u + (ax.pE + ax.pF) * v + (ax.pH - ax.pG) * w;
+    dy[2] = -t.sth * u - ax.k1 * v + ax.k2 * w;
     float tq = t.sph * q + t.cph * r;
     dy[3] = pp + t.sth * icd * tq;
     dy[4] = t.cph * q - t.sph * r;
@@ -254,20 +264,24 @@ __device__ __forceinline__ Trig6 trig6(const float* y) {
 }
 
 // One RHS evaluation in FAITHFUL mode = BlueROV2Heavy6DoF.derivs (6DoF.py:406-442), PID state mutated.
+// timeHistory columns F0..F5 (controller output) and u0..u7 (rpm) of the LAST derivs call of a step (6DoF.py:578-587)
+template <class PP>
+__device__ __forceinline__ void write_aux6(PP p, const float* u, const float* cv, float* aux_row) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) aux_row[q] = u[q];
+#pragma unroll
+    for (int q = 0; q < 8; q++) aux_row[6 + q] = force_to_rpm(p, cv[q]);
+}
+
 template <bool SYM, bool FLOW, bool HAS_DT, bool USE_INC, class PP>
 __device__ __forceinline__ void derivs6(PP p, const float* y, const float* sp, Pid6& pid, float dtp, float inv_den,
-                                        const float* dpose, float2 cur, float* dy, float* gcf, float* cv_raw, bool keep) {
+                                        const float* dpose, bool inc_valid, float2 cur, float* dy, float* aux_row) {
     Trig6 t = trig6(y);
     Axes ax = body_axes(t);
     float u[6], F[8], cv[8];
-    pid6<HAS_DT, USE_INC>(p, y, sp, pid, dtp, inv_den, dpose, u);
+    pid6<HAS_DT, USE_INC>(p, y, sp, pid, dtp, inv_den, dpose, inc_valid, u);
     allocate6<SYM>(p, ax, u, F, cv);
-    if (keep) {  // wave-uniform: side outputs of the last RHS call of the step (timeHistory columns)
-#pragma unroll
-        for (int i = 0; i < 6; i++) gcf[i] = u[i];
-#pragma unroll
-        for (int i = 0; i < 8; i++) cv_raw[i] = cv[i];
-    }
+    if (aux_row) write_aux6(p, u, cv, aux_row);  // wave-uniform: last RHS call of the step, aux enabled
     dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, dy);
 }
 
@@ -307,16 +321,17 @@ __device__ __forceinline__ void random_init6(uint64_t seed, int64_t gid, uint32_
 enum { R6_Y = 0, R6_EOLD = 12, R6_EINT = 18, R6_SP = 24, R6_PATH = 30, R6_TOFF = 36, R6_ISTEP = 37, R6_WORDS = 38 };
 
 template <class PP, bool SYM, bool ZOH, bool FLOW>
-__global__ __launch_bounds__(MVRL_BLOCK) void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
+__global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
-    const uint32_t i = blockIdx.x * MVRL_BLOCK + threadIdx.x;
-    if (i >= (uint32_t)io.n) return;
+    const uint32_t i_in = blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i_in >= (uint32_t)io.n) return;
     // plane k of env i = state[k * n + i] with a 32-bit element index: the access lowers to the
     // `global_load_dword v, v_off, s[base:base+1]` form (uniform 64-bit base in SGPRs + one 32-bit VGPR offset)
     // instead of a 64-bit VGPR address pair per plane.  The host guarantees words * n < 2^30.
     const uint32_t n32 = (uint32_t)io.n;
     char* const stb = reinterpret_cast<char*>(io.state);
-#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) << 2)))
+#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) << 2)))
+#define LANE i_in
 
     float y[12], sp[6], path[6];
     Pid6 pid;
@@ -324,15 +339,13 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_step_kernel(const Rov6Dev* __
     for (int k = 0; k < 12; k++) y[k] = ST(R6_Y + k);
 #pragma unroll
     for (int k = 0; k < 6; k++) { pid.eold[k] = ST(R6_EOLD + k); pid.eint[k] = ST(R6_EINT + k); }
-#pragma unroll
-    for (int k = 0; k < 6; k++) path[k] = ST(R6_PATH + k);
     int istep = __float_as_int(ST(R6_ISTEP));
 
     if (io.fixed_sp) {  // 6DoF.py:536-541
 #pragma unroll
         for (int k = 0; k < 6; k++) sp[k] = ST(R6_SP + k);
     } else {            // 6DoF.py:545-552
-        const float2* ap = reinterpret_cast<const float2*>(io.actions + (size_t)i * 6);
+        const float2* ap = reinterpret_cast<const float2*>(io.actions + (size_t)i_in * 6);
         float2 a01 = ap[0], a23 = ap[1], a45 = ap[2];
         sp[0] = fmaf(a01.x, p->act_scale[0], y[0]); sp[1] = fmaf(a01.y, p->act_scale[1], y[1]);
         sp[2] = fmaf(a23.x, p->act_scale[2], y[2]); sp[3] = fmaf(a23.y, p->act_scale[3], y[3]);
@@ -354,25 +367,24 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_step_kernel(const Rov6Dev* __
     const float h = io.dt / (float)io.n_sub;
     const float hh = 0.5f * h, h6 = h / 6.f;
     const float inv_hh = 1.0f / hh;
-    float gcf[6] = {0, 0, 0, 0, 0, 0}, cvr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool want_aux = (io.aux != nullptr);
+    float* const aux_row = io.aux ? io.aux + (size_t)i_in * 14 : nullptr;
     // pose increment between the last PID call of a sub-step and the first of the next; not known across env steps
-    // (new set-point, angle wrap): 1e30 fails pid6's consistency test, which then uses the rounded difference
-    float inc_prev[6] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+    // (new set-point, angle wrap): the first call of a step uses the rounded difference (inc_valid = false)
+    float inc_prev[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[12], acc[12], yt[12];
-        const bool last = want_aux && (ks == io.n_sub - 1);
+        float* const aux_last = (ks == io.n_sub - 1) ? aux_row : nullptr;
         if (ZOH) {
             // PID + allocation once per sub-step; t - tOld = h except for the very first call after reset (= 0)
             Trig6 t = trig6(y);
             Axes ax = body_axes(t);
             float u[6], F[8];
             const bool very_first = first && (ks == 0);
-            if (very_first) pid6<false, false>(p, y, sp, pid, 0.f, 1e9f, nullptr, u);
-            else pid6<true, false>(p, y, sp, pid, h, 1.0f / h, nullptr, u);
-            allocate6<SYM>(p, ax, u, F, cvr);
-#pragma unroll
-            for (int q = 0; q < 6; q++) gcf[q] = u[q];
+            if (very_first) pid6<false, false>(p, y, sp, pid, 0.f, 1e9f, nullptr, false, u);
+            else pid6<true, true>(p, y, sp, pid, h, 1.0f / h, inc_prev, ks > 0, u);
+            float cvz[8];
+            allocate6<SYM>(p, ax, u, F, cvz);
+            if (aux_last) write_aux6(p, u, cvz, aux_last);
             dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, k);
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
@@ -383,30 +395,32 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_step_kernel(const Rov6Dev* __
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
             dynamics_only6<SYM, FLOW>(p, yt, F, cur, k);
+#pragma unroll
+            for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (acc[q] + k[q]);  // pose change over this sub-step
         } else {
             // stage times: t, t+h/2, t+h/2, t+h  ->  t - tOld = 0, h/2, 0, h/2 (the previous call was at t).
             // dp = pose increment since the previous PID call, from the stage slopes (see pid6).
             float dp[6];
 #pragma unroll
-            for (int q = 0; q < 6; q++) dp[q] = inc_prev[q];  // 1e30 on the first stage of the env step: "unknown"
-            derivs6<SYM, FLOW, false, true>(p, y, sp, pid, 0.f, 1e9f, dp, cur, k, gcf, cvr, false);
+            for (int q = 0; q < 6; q++) dp[q] = inc_prev[q];
+            derivs6<SYM, FLOW, false, true>(p, y, sp, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr);
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
 #pragma unroll
             for (int q = 0; q < 6; q++) dp[q] = hh * k[q];                       // (y + hh k1) - y
-            derivs6<SYM, FLOW, true, true>(p, yt, sp, pid, hh, inv_hh, dp, cur, k, gcf, cvr, false);
+            derivs6<SYM, FLOW, true, true>(p, yt, sp, pid, hh, inv_hh, dp, true, cur, k, nullptr);
             float d2[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }  // hh (k2 - k1)
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
-            derivs6<SYM, FLOW, false, true>(p, yt, sp, pid, 0.f, 1e9f, dp, cur, k, gcf, cvr, false);
+            derivs6<SYM, FLOW, false, true>(p, yt, sp, pid, 0.f, 1e9f, dp, true, cur, k, nullptr);
             float d3[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }          // h k3 - hh k2
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
-            derivs6<SYM, FLOW, true, true>(p, yt, sp, pid, hh, inv_hh, dp, cur, k, gcf, cvr, last);
+            derivs6<SYM, FLOW, true, true>(p, yt, sp, pid, hh, inv_hh, dp, true, cur, k, aux_last);
 #pragma unroll
             for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (acc[q] + k[q]) - d3[q];            // y_new - (y + h k3)
         }
@@ -415,18 +429,20 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_step_kernel(const Rov6Dev* __
     }
     // 6DoF.py:560
     y[3] = mod_two_pi(y[3]); y[4] = mod_two_pi(y[4]); y[5] = mod_two_pi(y[5]);
+    // The epilogue addresses the same SoA planes as the prologue.  Left alone, LLVM keeps all ~40 prologue
+    // addresses alive in VGPR pairs across the whole RK4 loop (~75 registers, the difference between 2 and 3 waves
+    // per SIMD) instead of recomputing them; hiding the lane index behind an empty asm makes it recompute.
+    uint32_t i = i_in;
+    asm volatile("" : "+v"(i));
+#undef LANE
+#define LANE i
 
+#pragma unroll
+    for (int k = 0; k < 6; k++) path[k] = ST(R6_PATH + k);  // only the observation needs the way-points
     float o[9];
     observe6(p, y, path, sp, o);
     const bool done = istep >= io.max_steps;  // 6DoF.py:569-571
 
-    if (want_aux) {  // timeHistory columns F0..F5, u0..u7 (6DoF.py:578-587)
-        float* ax = io.aux + (size_t)i * 14;
-#pragma unroll
-        for (int q = 0; q < 6; q++) ax[q] = gcf[q];
-#pragma unroll
-        for (int q = 0; q < 8; q++) ax[6 + q] = force_to_rpm(p, cvr[q]);
-    }
     io.reward[i] = 0.f;  // 6DoF.py:575
     io.done[i] = done ? 3 : 0;  // bit 0 = done, bit 1 = time limit (TimeLimit.truncated)
 

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Build tuning variants of libmvrl.so (different launch bounds / compiler flags) into gpurun_out/variants/ and,
+with `run`, time the C4/C3 workloads with each of them (MVRL_LIB selects the library)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "variants_build")  # *.so is git-ignored; gpurun_out/ does not travel to the GPU box
+VARIANTS = {
+    "base": dict(extra=[], drop=()),
+    "slp": dict(extra=[], drop=("-fno-slp-vectorize",)),
+    "w2": dict(extra=["-DMVRL_MIN_WAVES=2"], drop=()),
+    "w3": dict(extra=["-DMVRL_MIN_WAVES=3"], drop=()),
+    "w4": dict(extra=["-DMVRL_MIN_WAVES=4"], drop=()),
+    "w2slp": dict(extra=["-DMVRL_MIN_WAVES=2"], drop=("-fno-slp-vectorize",)),
+    "fast": dict(extra=["-ffast-math"], drop=()),
+    "fastnative": dict(extra=["-ffast-math", "-DMVRL_NATIVE_TRIG"], drop=()),
+    "w4fast": dict(extra=["-ffast-math", "-DMVRL_MIN_WAVES=4"], drop=()),
+    "native": dict(extra=["-DMVRL_NATIVE_TRIG"], drop=()),
+    "finite": dict(extra=["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"], drop=()),
+    "w3finite": dict(extra=["-DMVRL_MIN_WAVES=3", "-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"], drop=()),
+}
+
+
+def build_all(names):
+    from marinevehiclereinforcementlearning_amd import build
+    os.makedirs(OUT, exist_ok=True)
+
+    def one(name):
+        v = VARIANTS[name]
+        return build.build_lib(extra_flags=v["extra"], out=os.path.join(OUT, f"libmvrl_{name}.so"), drop_flags=v["drop"])
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        print(list(ex.map(one, names)))
+
+
+def run_all(names):
+    for name in names:
+        env = dict(os.environ, MVRL_LIB=os.path.join(OUT, f"libmvrl_{name}.so"))
+        for wlk in ("c4", "c3"):
+            r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", wlk, "--steps", "100", "--warmup",
+                                "10", "--no-cpu-baseline"], env=env, capture_output=True, text=True)
+            import json
+            try:
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                print(f"{name:8s} {wlk}: {j['value']:.3e} env-steps/s  {j['roofline']['kernel_us_per_launch']:.1f} us/launch", flush=True)
+            except Exception:  # noqa: BLE001
+                print(name, wlk, "FAILED", r.stderr[-400:], flush=True)
+
+
+if __name__ == "__main__":
+    names = [a for a in sys.argv[2:]] or list(VARIANTS)
+    (build_all if sys.argv[1] == "build" else run_all)(names)
