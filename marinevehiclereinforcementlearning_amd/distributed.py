@@ -80,7 +80,8 @@ class OutputGather:
                 dist.gather(self.send, gather_list=None, dst=self.root, group=self.group)
 
     def unpack(self):
-        """On root (or everywhere in mode "all"): (obs[N, obs_dim], reward[N], done[N] u8) in global env order."""
+        """On root (or everywhere in mode "all"): (obs[N, obs_dim], reward[N], done[N] u8) in global env order.
+        obs and reward are VIEWS into the receive buffer: valid until the next exchange."""
         if self.recv is None:
             return None
         if self.even:

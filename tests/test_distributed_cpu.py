@@ -1,0 +1,106 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` process group, contiguous sharding, the per-step gather of
+(obs, reward, done) to rank 0 / to all ranks, ragged shards.  The per-rank stepper here is the CPU oracle (tests may
+use it); on the GPU box the same ShardedVecEnv wraps MarineVecEnv (tests/test_gpu_api.py, bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from marinevehiclereinforcementlearning_amd import distributed as D
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleShard:
+    """CPU stepper with the step_tensors/reset_tensors interface; per-env inputs are functions of the GLOBAL id."""
+
+    def __init__(self, offset, count, n_global, steps_seed=3):
+        from oracle import oracle as orc
+        self.env = orc.OracleRovEnv(6, count, "f64", n_substeps=2, max_steps=10 ** 9)
+        rng = np.random.default_rng(5)
+        init = np.concatenate([(rng.random((n_global, 6)) - 0.5) * 10, rng.random((n_global, 3)) * 2 * np.pi], axis=1)
+        self.init = init[offset:offset + count]
+
+    def reset_tensors(self):
+        return torch.from_numpy(self.env.reset(self.init)).float()
+
+    def step_tensors(self, actions):
+        o, r, d = self.env.step(actions.numpy().astype(np.float64))
+        return torch.from_numpy(o).float(), torch.from_numpy(r).float(), torch.from_numpy(d)
+
+
+def worker(rank, world, port, n_global, mode, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    env = D.ShardedVecEnv(lambda off, cnt, rk: OracleShard(off, cnt, n_global), n_global, 9, torch.device("cpu"), gather=mode)
+    acts = torch.from_numpy(np.random.default_rng(9).uniform(-1, 1, size=(4, n_global, 6))).float()
+    def keep(x):  # gathered outputs are views into the receive buffer, valid until the next call
+        return None if x is None else (x.clone() if torch.is_tensor(x) else tuple(t.clone() for t in x))
+    outs = [keep(env.reset())]
+    for s in range(4):
+        outs.append(keep(env.step(acts[s, env.offset:env.offset + env.count])))
+    if rank == 0 or mode == "all":
+        q.put((rank, outs[0].numpy().copy(), [tuple(t.numpy().copy() for t in o) for o in outs[1:]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_world(n_global, mode, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, n_global, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world if mode == "all" else 1)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def single_process(n_global):
+    sh = OracleShard(0, n_global, n_global)
+    acts = torch.from_numpy(np.random.default_rng(9).uniform(-1, 1, size=(4, n_global, 6))).float()
+    out0 = sh.reset_tensors().numpy()
+    outs = [tuple(t.numpy() for t in sh.step_tensors(acts[s])) for s in range(4)]
+    return out0, outs
+
+
+def test_shard_range_partitions_everything():
+    for n, w in [(10, 4), (8388608, 8), (7, 8), (1, 1), (1048577, 2)]:
+        rs = [D.shard_range(n, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and sum(c for _, c in rs) == n
+        assert all(rs[i][0] + rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+        assert max(c for _, c in rs) - min(c for _, c in rs) <= 1
+
+
+@pytest.mark.parametrize("n_global,mode", [(16, "root"), (11, "root"), (11, "all")])
+def test_two_rank_gather_equals_single_process(n_global, mode):
+    """Concatenation of the shards == the unsharded batch, bit for bit (even and ragged shards)."""
+    ref0, ref = single_process(n_global)
+    for rank, got0, got in run_world(n_global, mode):
+        assert np.array_equal(got0, ref0)
+        for s in range(4):
+            assert np.array_equal(got[s][0], ref[s][0])
+            assert np.array_equal(got[s][1], ref[s][1])
+            assert np.array_equal(got[s][2], ref[s][2].astype(np.uint8))
+
+
+def test_gather_single_process_passthrough():
+    g = D.OutputGather(5, 3, torch.device("cpu"))
+    obs, rew, done = torch.rand(5, 3), torch.rand(5), torch.tensor([0, 1, 0, 3, 0], dtype=torch.uint8)
+    o, r, d = g(obs, rew, done)
+    assert torch.equal(o, obs) and torch.equal(r, rew) and torch.equal(d, done)
+    assert g.bytes_per_step() == 5 * 5 * 4
