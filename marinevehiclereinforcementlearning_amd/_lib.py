@@ -5,6 +5,7 @@ raises: there is deliberately no CPU fallback in the product path.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -38,6 +39,14 @@ def load(path=None):
     if _lib is not None:
         return _lib
     path = path or os.environ.get("MVRL_LIB", LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  If libmvrl.so pulled in the
+    # system copy first, a later `import torch` would bring up a second runtime that sees no GPU.  Importing torch
+    # first (when it is installed) makes both share torch's copy (same soname).
+    if "torch" not in sys.modules and os.environ.get("MVRL_NO_TORCH_PRELOAD") is None:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # noqa: BLE001 - torch is optional for the host-buffer API
+            pass
     if not os.path.exists(path):
         raise MvrlError(f"{path} not found - build it with `python -m marinevehiclereinforcementlearning_amd.build` "
                         "(needs hipcc; there is no CPU fallback)")
