@@ -103,7 +103,12 @@ def main():
                  f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
-    rank, world, local_rank = D.init_from_env("nccl")
+    # Rehearsal knobs for a 1-GPU box (never used by the driver): MVRL_BENCH_BACKEND=gloo lets two ranks share one
+    # card (RCCL refuses duplicate devices), MVRL_BENCH_SAME_DEVICE=1 maps every rank to cuda:0.
+    backend = os.environ.get("MVRL_BENCH_BACKEND", "nccl")
+    rank, world, local_rank = D.init_from_env(backend)
+    if os.environ.get("MVRL_BENCH_SAME_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if not os.path.exists(os.path.join(REPO, "marinevehiclereinforcementlearning_amd", "libmvrl.so")):

@@ -131,7 +131,7 @@ enum { R3_Y = 0, R3_EOLD = 6, R3_EINT = 9, R3_SP = 12, R3_PATH = 15, R3_TOFF = 1
 template <class PP, bool ZOH, bool FLOW>
 __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
-    const uint32_t i_in = blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    const uint32_t i_in = blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
     if (i_in >= (uint32_t)io.n) return;
     const uint32_t n32 = (uint32_t)io.n;  // see mvrl_rov6.hip: 32-bit byte offsets -> saddr addressing
     char* const stb = reinterpret_cast<char*>(io.state);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_reset_kernel(const Rov3Dev* _
 
 hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool zoh, bool flow,
                             hipStream_t stream) {
-    dim3 grid((unsigned)((io.n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    dim3 grid((unsigned)((io.n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
 #define MVRL_L3(PPT, Z, F) hipLaunchKernelGGL((rov3_step_kernel<PPT, Z, F>), grid, block, 0, stream, p, io, fl)
     if (baked) {
         if (zoh) { if (flow) MVRL_L3(const Rov3Baked*, true, true); else MVRL_L3(const Rov3Baked*, true, false); }

@@ -323,7 +323,7 @@ enum { R6_Y = 0, R6_EOLD = 12, R6_EINT = 18, R6_SP = 24, R6_PATH = 30, R6_TOFF =
 template <class PP, bool SYM, bool ZOH, bool FLOW>
 __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
-    const uint32_t i_in = blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    const uint32_t i_in = blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
     if (i_in >= (uint32_t)io.n) return;
     // plane k of env i = state[k * n + i] with a 32-bit element index: the access lowers to the
     // `global_load_dword v, v_off, s[base:base+1]` form (uniform 64-bit base in SGPRs + one 32-bit VGPR offset)
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_reset_kernel(const Rov6Dev* _
 // ---- host-side launchers ---------------------------------------------------------------------------
 hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool sym, bool zoh,
                             bool flow, hipStream_t stream) {
-    dim3 grid((unsigned)((io.n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    dim3 grid((unsigned)((io.n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
 #define MVRL_L6(S, Z, F) hipLaunchKernelGGL((rov6_step_kernel<CP6, S, Z, F>), grid, block, 0, stream, p, io, fl)
 #define MVRL_L6B(Z, F) hipLaunchKernelGGL((rov6_step_kernel<const Rov6Baked*, true, Z, F>), grid, block, 0, stream, p, io, fl)
     if (baked) {

@@ -71,6 +71,8 @@ class OutputGather:
             if self.recv is not None:
                 self.recv[0].copy_(self.send)
             return
+        if self.send.is_cuda and dist.get_backend(self.group) == "gloo":
+            return self._exchange_via_host()  # rehearsal path: gloo has no device-side gather
         if self.mode == "all":
             dist.all_gather_into_tensor(self.recv.view(-1, self.row), self.send, group=self.group)
         else:
@@ -78,6 +80,19 @@ class OutputGather:
                 dist.gather(self.send, gather_list=list(self.recv.unbind(0)), dst=self.root, group=self.group)
             else:
                 dist.gather(self.send, gather_list=None, dst=self.root, group=self.group)
+
+    def _exchange_via_host(self):
+        send = self.send.cpu()
+        if self.mode == "all":
+            out = torch.empty((self.world,) + tuple(send.shape), dtype=send.dtype)
+            dist.all_gather_into_tensor(out.view(-1, self.row), send, group=self.group)
+            self.recv.copy_(out)
+        elif self.rank == self.root:
+            parts = [torch.empty_like(send) for _ in range(self.world)]
+            dist.gather(send, gather_list=parts, dst=self.root, group=self.group)
+            self.recv.copy_(torch.stack(parts))
+        else:
+            dist.gather(send, gather_list=None, dst=self.root, group=self.group)
 
     def unpack(self):
         """On root (or everywhere in mode "all"): (obs[N, obs_dim], reward[N], done[N] u8) in global env order.

@@ -11,6 +11,13 @@ sys.path.insert(0, REPO)
 OUT = os.path.join(REPO, "variants_build")  # *.so is git-ignored; gpurun_out/ does not travel to the GPU box
 VARIANTS = {
     "base": dict(extra=[], drop=()),
+    "lds0": dict(extra=["-DMVRL_LDS_STATE=0"], drop=()),
+    "w4lds0": dict(extra=["-DMVRL_LDS_STATE=0", "-DMVRL_MIN_WAVES=4"], drop=()),
+    "blk256": dict(extra=["-DMVRL_STEP_BLOCK=256"], drop=()),
+    "w4blk256": dict(extra=["-DMVRL_STEP_BLOCK=256", "-DMVRL_MIN_WAVES=4"], drop=()),
+    "blk64": dict(extra=["-DMVRL_BLOCK=64"], drop=()),
+    "blk128": dict(extra=["-DMVRL_BLOCK=128"], drop=()),
+    "blk512": dict(extra=["-DMVRL_BLOCK=512"], drop=()),
     "slp": dict(extra=[], drop=("-fno-slp-vectorize",)),
     "w2": dict(extra=["-DMVRL_MIN_WAVES=2"], drop=()),
     "w3": dict(extra=["-DMVRL_MIN_WAVES=3"], drop=()),
