@@ -42,6 +42,16 @@ extern "C" {
 #define MVRL_CTRL_FAITHFUL 0 /* PID inside the RHS, evaluated (and mutated) at every RK stage - as 6DoF.py:418 */
 #define MVRL_CTRL_ZOH 1      /* PID + allocation once per sub-step, thruster rpm held over the stages          */
 
+/* ---- arithmetic / storage precision of a handle ---------------------------------------------------------- */
+#define MVRL_PREC_F32 0 /* fp32 state, arithmetic and ABI arrays (float*): the throughput path                  */
+#define MVRL_PREC_F64 1 /* fp64 everywhere (double*; use the *_f64 entry points): the exactness path, same kernel
+                           text widened (tools/gen_f64.py); reproduces the reference to ~1e-12                   */
+
+/* ---- time integrator of the 3/6-DoF models ------------------------------------------------------------- */
+#define MVRL_INTEG_RK4 0  /* classic RK4, n_substeps sub-steps per env step (this build's integrator)           */
+#define MVRL_INTEG_RK45 1 /* the reference's own: scipy solve_ivp(method="RK45", max_step=dt, rtol=atol=1e-3)
+                             restated per lane (6DoF.py:555-557, 3DoF.py:475-477); needs MVRL_PREC_F64         */
+
 /* ---- error codes --------------------------------------------------------------------------- */
 #define MVRL_OK 0
 #define MVRL_EINVAL (-1)  /* bad argument / configuration     */
@@ -133,6 +143,8 @@ typedef struct mvrl_config {
     int32_t auto_reset;     /* 1: SB3 VecEnv semantics - done lanes are re-initialised inside step */
     uint64_t seed;          /* counter-based RNG key for resets without explicit initial values */
     int32_t use_flow;       /* 1: sample the turbulence table each step (AUV: as the reference; 3/6-DoF: SURVEY 9.5) */
+    int32_t precision;      /* MVRL_PREC_* */
+    int32_t integrator;     /* MVRL_INTEG_* (3/6-DoF) */
     int32_t _pad;
     mvrl_rov6_params rov6;
     mvrl_rov3_params rov3;
@@ -164,8 +176,9 @@ void mvrl_destroy(mvrl_handle* h);
 /* Upload the scaled turbulence table (host float32 [n_t][n_y][n_x][2]).
  * Replaces the table held by ReconstructedFlow after scale() (flowGenerator.py:76-95). */
 int mvrl_set_flow(mvrl_handle* h, const float* table_host, const mvrl_flow_desc* desc);
-/* Same, table already resident on the handle's device (not copied; caller keeps it alive). */
-int mvrl_set_flow_dev(mvrl_handle* h, const float* table_dev, const mvrl_flow_desc* desc);
+int mvrl_set_flow_f64(mvrl_handle* h, const double* table_host, const mvrl_flow_desc* desc);
+/* Same, table already resident on the handle's device in the handle's precision (not copied; caller keeps it alive). */
+int mvrl_set_flow_dev(mvrl_handle* h, const void* table_dev, const mvrl_flow_desc* desc);
 
 /* ---- reset: replaces Env.reset (6DoF.py:485-529, 3DoF.py:411-453, verySimpleAuv.py:216-262) ----------
  * mask : n_envs bytes, non-zero = reset this env; NULL = all.
@@ -176,7 +189,9 @@ int mvrl_set_flow_dev(mvrl_handle* h, const float* table_dev, const mvrl_flow_de
  *              XactMult YactMult NactMult   (fixedInitialValues + the multipliers of verySimpleAuv.py:222-229,245)
  * obs  : [n_envs, obs_dim] out (rows of envs that were not reset are left untouched); may be NULL. */
 int mvrl_reset(mvrl_handle* h, const uint8_t* mask, const float* init, float* obs);
-int mvrl_reset_dev(mvrl_handle* h, const uint8_t* mask_dev, const float* init_dev, float* obs_dev, void* stream);
+int mvrl_reset_f64(mvrl_handle* h, const uint8_t* mask, const double* init, double* obs);
+/* device pointers in the handle's precision (float* for MVRL_PREC_F32, double* for MVRL_PREC_F64) */
+int mvrl_reset_dev(mvrl_handle* h, const uint8_t* mask_dev, const void* init_dev, void* obs_dev, void* stream);
 
 /* ---- step: replaces Env.step (6DoF.py:531-594, 3DoF.py:455-514, verySimpleAuv.py:264-410) -------------
  * and SB3 VecEnv.step_async/step_wait (called at tag/main_00_sbl.py:145-161 through agent.learn).
@@ -186,23 +201,31 @@ int mvrl_reset_dev(mvrl_handle* h, const uint8_t* mask_dev, const float* init_de
 int mvrl_step(mvrl_handle* h, const float* actions, float* obs, float* reward, uint8_t* done);
 int mvrl_step_async(mvrl_handle* h, const float* actions);
 int mvrl_step_wait(mvrl_handle* h, float* obs, float* reward, uint8_t* done);
-int mvrl_step_dev(mvrl_handle* h, const float* actions_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev,
+int mvrl_step_f64(mvrl_handle* h, const double* actions, double* obs, double* reward, uint8_t* done);
+int mvrl_step_dev(mvrl_handle* h, const void* actions_dev, void* obs_dev, void* reward_dev, uint8_t* done_dev,
                   void* stream);
 
 /* Observation of the step on which an env finished (SB3 infos[i]["terminal_observation"]); rows of envs
  * that did not finish on the last step are unspecified.  Only meaningful with auto_reset = 1. */
 int mvrl_get_terminal_obs(mvrl_handle* h, float* obs);
-int mvrl_get_terminal_obs_dev(mvrl_handle* h, float* obs_dev, void* stream);
+int mvrl_get_terminal_obs_f64(mvrl_handle* h, double* obs);
+int mvrl_get_terminal_obs_dev(mvrl_handle* h, void* obs_dev, void* stream);
 
-/* ---- raw state (checkpoint / parity tests): SoA [state_words][n_envs] float32 ------------------------ */
-int mvrl_get_state(mvrl_handle* h, float* buf, size_t n_floats);
-int mvrl_set_state(mvrl_handle* h, const float* buf, size_t n_floats);
+/* ---- raw state (checkpoint / parity tests): SoA [state_words][n_envs] in the handle's precision; the last
+ * plane is the step counter as an integer bit pattern (int32 in a float slot / int64 in a double slot) ---- */
+int mvrl_get_state(mvrl_handle* h, float* buf, size_t n_elems);
+int mvrl_set_state(mvrl_handle* h, const float* buf, size_t n_elems);
+int mvrl_get_state_f64(mvrl_handle* h, double* buf, size_t n_elems);
+int mvrl_set_state_f64(mvrl_handle* h, const double* buf, size_t n_elems);
 
 /* Per-step side outputs the reference keeps in timeHistory (6DoF.py:578-587: F0..F5, u0..u7; 3DoF: F0..F2,u0..u3;
  * verySimpleAuv.py:389-403: Fx,Fy,N,u_current,v_current,rmsAc,r0..r4).  Enable BEFORE stepping;
  * aux row = [n_envs, aux_dim] f32 with aux_dim = 14 (ROV6) / 7 (ROV3) / 11 (AUV). */
 int mvrl_enable_aux(mvrl_handle* h, int32_t enable);
 int mvrl_get_aux(mvrl_handle* h, float* aux);
+int mvrl_get_aux_f64(mvrl_handle* h, double* aux);
+/* MVRL_INTEG_RK45 only: RHS evaluations each env spent in its last step (scipy's nfev). */
+int mvrl_get_nfev(mvrl_handle* h, int32_t* nfev);
 
 /* ---- stand-alone turbulence-field operators ----------------------------------------------------------- */
 /* ReconstructedFlow.interp (flowGenerator.py:97-136) for n query points; table is host f32

@@ -26,6 +26,9 @@ SYMBOLS = [
     "mvrl_get_state", "mvrl_set_state", "mvrl_enable_aux", "mvrl_get_aux", "mvrl_flow_interp", "mvrl_flow_reconstruct",
     "mvrl_fill_uniform_dev", "mvrl_timing_begin", "mvrl_timing_end", "mvrl_dev_alloc", "mvrl_dev_free",
     "mvrl_dev_upload", "mvrl_dev_download", "mvrl_synchronize",
+    # fp64 twins of the host-buffer entry points + RK45 diagnostics
+    "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
+    "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev",
 ]
 
 
@@ -87,6 +90,14 @@ def load(path=None):
     lib.mvrl_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
     lib.mvrl_dev_download.argtypes = [vp, vp, vp, C.c_size_t]
     lib.mvrl_synchronize.argtypes = [vp]
+    lib.mvrl_set_flow_f64.argtypes = [vp, vp, C.POINTER(P.FlowDesc)]
+    lib.mvrl_reset_f64.argtypes = [vp, vp, vp, vp]
+    lib.mvrl_step_f64.argtypes = [vp, vp, vp, vp, vp]
+    lib.mvrl_get_terminal_obs_f64.argtypes = [vp, vp]
+    lib.mvrl_get_state_f64.argtypes = [vp, vp, C.c_size_t]
+    lib.mvrl_set_state_f64.argtypes = [vp, vp, C.c_size_t]
+    lib.mvrl_get_aux_f64.argtypes = [vp, vp]
+    lib.mvrl_get_nfev.argtypes = [vp, vp]
     if lib.mvrl_abi_version() != P.ABI_VERSION:
         raise MvrlError("libmvrl.so ABI version does not match the Python package")
     _lib = lib
@@ -104,11 +115,15 @@ def device_count():
     return int(load().mvrl_device_count())
 
 
-def _f32(a, shape=None):
-    a = np.ascontiguousarray(a, dtype=np.float32)
+def _real(a, dtype, shape=None):
+    a = np.ascontiguousarray(a, dtype=dtype)
     if shape is not None and a.shape != tuple(shape):
         raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
     return a
+
+
+def _f32(a, shape=None):
+    return _real(a, np.float32, shape)
 
 
 def flow_desc(n_t, n_y, n_x, dt, dx, dy):
@@ -118,20 +133,30 @@ def flow_desc(n_t, n_y, n_x, dt, dx, dy):
 
 
 class Handle:
-    """Owning wrapper of one mvrl_handle (one shard of environments on one GPU)."""
+    """Owning wrapper of one mvrl_handle (one shard of environments on one GPU).
+
+    The handle's precision (cfg.precision) decides the dtype of every real-valued array that crosses the ABI
+    (float32 -> the plain entry points, float64 -> the *_f64 ones)."""
 
     def __init__(self, cfg):
         self.lib = load()
         self.cfg = cfg
         self.model = int(cfg.model)
         self.n = int(cfg.n_envs)
+        self.f64 = int(cfg.precision) == P.PREC_F64
+        self.dtype = np.float64 if self.f64 else np.float32
+        self.itype = np.int64 if self.f64 else np.int32   # view of the step-counter plane
+        self._sfx = "_f64" if self.f64 else ""
         self.act_dim, self.obs_dim, self.init_dim, self.state_words, self.aux_dim = P.MODEL_DIMS[self.model]
         h = C.c_void_p()
         check(self.lib.mvrl_create(C.byref(cfg), C.byref(h)))
         self.h = h
-        self._obs = np.zeros((self.n, self.obs_dim), np.float32)
-        self._rew = np.zeros(self.n, np.float32)
+        self._obs = np.zeros((self.n, self.obs_dim), self.dtype)
+        self._rew = np.zeros(self.n, self.dtype)
         self._done = np.zeros(self.n, np.uint8)
+
+    def _fn(self, name):
+        return getattr(self.lib, name + self._sfx)
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -151,11 +176,11 @@ class Handle:
 
     # -- flow -------------------------------------------------------------------------------------
     def set_flow(self, table_uv, dt, dx, dy):
-        t = _f32(table_uv)
+        t = _real(table_uv, self.dtype)
         if t.ndim != 4 or t.shape[3] != 2:
             raise ValueError("flow table must be [n_t, n_y, n_x, 2]")
         d = flow_desc(t.shape[0], t.shape[1], t.shape[2], dt, dx, dy)
-        check(self.lib.mvrl_set_flow(self.h, t.ctypes.data, C.byref(d)), self.h)
+        check(self._fn("mvrl_set_flow")(self.h, t.ctypes.data, C.byref(d)), self.h)
 
     def set_flow_dev(self, ptr, n_t, n_y, n_x, dt, dx, dy):
         d = flow_desc(n_t, n_y, n_x, dt, dx, dy)
@@ -164,19 +189,22 @@ class Handle:
     # -- host-buffer API --------------------------------------------------------------------------
     def reset(self, mask=None, init=None, obs_out=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.n)
-        ini = None if init is None else _f32(init, (self.n, self.init_dim))
+        ini = None if init is None else _real(init, self.dtype, (self.n, self.init_dim))
         obs = self._obs if obs_out is None else obs_out
-        check(self.lib.mvrl_reset(self.h, None if m is None else m.ctypes.data, None if ini is None else ini.ctypes.data,
-                                  obs.ctypes.data), self.h)
+        assert obs.dtype == self.dtype
+        check(self._fn("mvrl_reset")(self.h, None if m is None else m.ctypes.data,
+                                     None if ini is None else ini.ctypes.data, obs.ctypes.data), self.h)
         return obs
 
     def step(self, actions):
-        a = None if actions is None else _f32(actions, (self.n, self.act_dim))
-        check(self.lib.mvrl_step(self.h, None if a is None else a.ctypes.data, self._obs.ctypes.data,
-                                 self._rew.ctypes.data, self._done.ctypes.data), self.h)
+        a = None if actions is None else _real(actions, self.dtype, (self.n, self.act_dim))
+        check(self._fn("mvrl_step")(self.h, None if a is None else a.ctypes.data, self._obs.ctypes.data,
+                                    self._rew.ctypes.data, self._done.ctypes.data), self.h)
         return self._obs, self._rew, self._done
 
     def step_async(self, actions):
+        if self.f64:
+            raise MvrlError("step_async/step_wait are fp32-only; fp64 handles use step()")
         a = None if actions is None else _f32(actions, (self.n, self.act_dim))
         check(self.lib.mvrl_step_async(self.h, None if a is None else a.ctypes.data), self.h)
 
@@ -186,25 +214,34 @@ class Handle:
         return self._obs, self._rew, self._done
 
     def terminal_obs(self):
-        out = np.zeros((self.n, self.obs_dim), np.float32)
-        check(self.lib.mvrl_get_terminal_obs(self.h, out.ctypes.data), self.h)
+        out = np.zeros((self.n, self.obs_dim), self.dtype)
+        check(self._fn("mvrl_get_terminal_obs")(self.h, out.ctypes.data), self.h)
         return out
 
     def get_state(self):
-        buf = np.zeros((self.state_words, self.n), np.float32)
-        check(self.lib.mvrl_get_state(self.h, buf.ctypes.data, buf.size), self.h)
+        buf = np.zeros((self.state_words, self.n), self.dtype)
+        check(self._fn("mvrl_get_state")(self.h, buf.ctypes.data, buf.size), self.h)
         return buf
 
     def set_state(self, buf):
-        b = _f32(buf, (self.state_words, self.n))
-        check(self.lib.mvrl_set_state(self.h, b.ctypes.data, b.size), self.h)
+        b = _real(buf, self.dtype, (self.state_words, self.n))
+        check(self._fn("mvrl_set_state")(self.h, b.ctypes.data, b.size), self.h)
+
+    def step_counter(self, state=None):
+        st = self.get_state() if state is None else state
+        return st[-1].view(self.itype)
 
     def enable_aux(self, on=True):
         check(self.lib.mvrl_enable_aux(self.h, 1 if on else 0), self.h)
 
     def get_aux(self):
-        out = np.zeros((self.n, self.aux_dim), np.float32)
-        check(self.lib.mvrl_get_aux(self.h, out.ctypes.data), self.h)
+        out = np.zeros((self.n, self.aux_dim), self.dtype)
+        check(self._fn("mvrl_get_aux")(self.h, out.ctypes.data), self.h)
+        return out
+
+    def get_nfev(self):
+        out = np.zeros(self.n, np.int32)
+        check(self.lib.mvrl_get_nfev(self.h, out.ctypes.data), self.h)
         return out
 
     # -- device-pointer API (ints = raw device addresses, e.g. torch.Tensor.data_ptr()) -------------

@@ -13,20 +13,26 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvrl.so")
-SOURCES = ["mvrl_abi.hip", "mvrl_rov6.hip", "mvrl_rov3.hip", "mvrl_auv.hip", "mvrl_flow.hip"]
-HEADERS = ["mvrl_device.hpp", "mvrl_kernels.hpp", "mvrl_baked.inc"]
+SOURCES = ["mvrl_abi.hip", "mvrl_rov6.hip", "mvrl_rov3.hip", "mvrl_auv.hip", "mvrl_flow.hip",
+           # fp64 twins, generated from the fp32 sources by tools/gen_f64.py at build time
+           "gen/mvrl_rov6_f64.hip", "gen/mvrl_rov3_f64.hip", "gen/mvrl_auv_f64.hip"]
+HEADERS = ["mvrl_device.hpp", "mvrl_kernels.hpp", "mvrl_baked.inc", "mvrl_rk45.hpp", "gen/mvrl_device_f64.hpp",
+           "gen/mvrl_kernels_f64.hpp", "gen/mvrl_baked_f64.inc"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: v_pk_* packing costs more constant moves than it saves here (measured -16 %);
 # -ffast-math: reassociation + no-NaN/Inf folding (structural zeros of the baked constants disappear), +10 %; parity
 # tests pass with the same margins with and without it (DESIGN.md "compiler flags").
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-ffast-math", f"--offload-arch={ARCH}", "-I", CSRC, "-Wall",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-ffast-math", f"--offload-arch={ARCH}", "-I", CSRC, "-I",
+         os.path.join(CSRC, "gen"), "-Wall",
          "-Wno-unused-function"]
 
 
 def _gen_baked():
     sys.path.insert(0, os.path.join(REPO, "tools"))
     import gen_baked
-    return gen_baked.main()
+    import gen_f64
+    gen_baked.main()
+    return gen_f64.main()
 
 
 def _stale(target, deps):
@@ -50,7 +56,7 @@ def build_lib(force=False, verbose=False, extra_flags=None, out=None, drop_flags
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
             jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
 
@@ -63,7 +69,7 @@ def build_lib(force=False, verbose=False, extra_flags=None, out=None, drop_flags
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(objdir, os.path.basename(s).replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB

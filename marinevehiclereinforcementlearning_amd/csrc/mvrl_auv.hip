@@ -73,7 +73,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     float hist[30];
 #pragma unroll
     for (int q = 0; q < 30; q++) hist[q] = ST(AV_HIST + q);
-    int istep = __float_as_int(ST(AV_ISTEP));
+    int istep = unpack_int(ST(AV_ISTEP));
     const float* ap = io.actions + (size_t)i * 3;
     const float a0 = ap[0], a1 = ap[1], a2 = ap[2];
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     for (int q = 0; q < 11; q++) io.obs[(size_t)i * 11 + q] = o[q];
     ST(AV_X) = x; ST(AV_Y) = y; ST(AV_PSI) = psi; ST(AV_VX) = vx; ST(AV_VY) = vy; ST(AV_R) = r;
     ST(AV_HERR_O) = herr_o; ST(AV_PERR_O) = perr_ox; ST(AV_PERR_O + 1) = perr_oy;
-    ST(AV_ISTEP) = __int_as_float(istep);
+    ST(AV_ISTEP) = pack_int(istep);
 #undef ST
 }
 
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_reset_kernel(const AuvDev p, f
     st[AV_TOFF * n] = v[4];
 #pragma unroll
     for (int q = 0; q < 30; q++) st[(AV_HIST + q) * n] = 0.f;
-    st[AV_ISTEP * n] = __int_as_float(0);
+    st[AV_ISTEP * n] = pack_int(0);
     if (obs) {
         float o[11];
         observe_auv(x, y, psi, 0.f, 0.f, 0.f, tgt, herr_o, perr_ox, perr_oy, o);

@@ -29,10 +29,24 @@ namespace mvrl {
 __device__ __forceinline__ float fsign(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
 
-// 2*pi split for Cody-Waite style reduction: TWO_PI_HI + TWO_PI_LO == 2*pi to ~1e-15
+// This file (like mvrl_rov6/rov3/auv.hip and mvrl_kernels.hpp) is written for fp32; tools/gen_f64.py derives the fp64
+// build (namespace mvrl64, every `float` -> `double`, f-suffixed literals and libm names widened) from the same text.
+// The few places where the two precisions must differ are under MVRL_F64.
+#ifndef MVRL_F64
+#define MVRL_F64 0
+#endif
+// 2*pi split for Cody-Waite style reduction: TWO_PI_HI + TWO_PI_LO == 2*pi beyond working precision
+#if MVRL_F64
+#define MVRL_TWO_PI_HI 6.283185307179586
+#define MVRL_TWO_PI_LO 2.4492935982947064e-16
+#define MVRL_INV_TWO_PI 0.15915494309189535
+#define MVRL_PI 3.141592653589793
+#else
 #define MVRL_TWO_PI_HI 6.2831855f
 #define MVRL_TWO_PI_LO (-1.7484555e-7f)
 #define MVRL_INV_TWO_PI 0.15915494f
+#define MVRL_PI 3.14159265f
+#endif
 
 // Python float modulo x % (2*pi) -> [0, 2*pi)   (resources.py:92-93, 6DoF.py:560)
 __device__ __forceinline__ float mod_two_pi(float x) {
@@ -53,14 +67,18 @@ __device__ __forceinline__ float angle_error(float psi_d, float psi) {
     const float q = rintf(d * MVRL_INV_TWO_PI);
     float r = fmaf(-q, MVRL_TWO_PI_HI, d);
     r = fmaf(-q, MVRL_TWO_PI_LO, r);
-    r = (r >= 3.14159265f) ? r - MVRL_TWO_PI_HI : r;
-    r = (r < -3.14159265f) ? r + MVRL_TWO_PI_HI : r;
+    r = (r >= MVRL_PI) ? r - MVRL_TWO_PI_HI : r;
+    r = (r < -MVRL_PI) ? r + MVRL_TWO_PI_HI : r;
     return r;
 }
 
 // sin & cos with ~1 ulp accuracy for |x| up to a few thousand radians, branch-free (Cody-Waite reduction by
 // pi/2 in three exact-product pieces + Cephes-style minimax polynomials on [-pi/4, pi/4]).
 __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
+#if MVRL_F64
+    ::sincos(x, &s, &c);  // fp64 build: the library routine
+    return;
+#endif
 #ifdef MVRL_NATIVE_TRIG
     // hardware v_sin_f32 / v_cos_f32 (argument in revolutions): ~4x fewer issue slots, ~1e-6 absolute accuracy
     const float rev = x * MVRL_INV_TWO_PI;
@@ -84,6 +102,15 @@ __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
     s = (n & 2) ? -s1 : s1;
     c = ((n + 1) & 2) ? -c1 : c1;
 }
+
+// the step counter shares the SoA state buffer with the real-valued planes: stored as an integer bit pattern
+#if MVRL_F64
+__device__ __forceinline__ int unpack_int(double v) { return (int)__double_as_longlong(v); }
+__device__ __forceinline__ double pack_int(int i) { return __longlong_as_double((long long)i); }
+#else
+__device__ __forceinline__ int unpack_int(float v) { return __float_as_int(v); }
+__device__ __forceinline__ float pack_int(int i) { return __int_as_float(i); }
+#endif
 
 // ---- Philox4x32-10 counter-based RNG (Salmon et al. 2011) -----------------------------------------
 // Streams are keyed by (seed) and counted by (global env id, epoch, slot) so results do not depend on how
@@ -226,6 +253,7 @@ struct StepIO {
     uint8_t* done;          // [n]
     float* term_obs;        // [n][obs_dim] or nullptr
     float* aux;             // [n][aux_dim] or nullptr
+    int* nfev;              // [n] RHS evaluations of the adaptive integrator, or nullptr
     int64_t n;
     int64_t env_offset;
     uint64_t seed;

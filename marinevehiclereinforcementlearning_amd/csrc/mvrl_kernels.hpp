@@ -5,12 +5,12 @@
 namespace mvrl {
 
 hipError_t launch_rov6_step(const Rov6Dev* p_dev, const StepIO& io, const FlowDev& fl, bool baked, bool sym, bool zoh,
-                            bool flow, hipStream_t stream);
+                            bool flow, bool rk45, hipStream_t stream);
 hipError_t launch_rov6_reset(const Rov6Dev* p_dev, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
                              uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream);
 
 hipError_t launch_rov3_step(const Rov3Dev* p_dev, const StepIO& io, const FlowDev& fl, bool baked, bool zoh, bool flow,
-                            hipStream_t stream);
+                            bool rk45, hipStream_t stream);
 hipError_t launch_rov3_reset(const Rov3Dev* p_dev, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
                              uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream);
 
@@ -27,6 +27,6 @@ hipError_t launch_flow_reconstruct(const float* modes_re, const float* modes_im,
 hipError_t launch_fill_uniform(float* dst, int64_t n, uint64_t seed, uint64_t counter, float lo, float hi,
                                hipStream_t stream);
 
-enum { R6_WORDS_ = 38, R3_WORDS_ = 21, AUV_WORDS_ = 54 };
+enum { R6_WORDS_ = 40, R3_WORDS_ = 23, AUV_WORDS_ = 53 };
 
 }  // namespace mvrl

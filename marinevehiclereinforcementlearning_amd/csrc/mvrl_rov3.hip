@@ -4,6 +4,9 @@
 // 4-thruster allocation and jet-drag augment (dynamicsModel_BlueROV2_Heavy_3DoF.py:114-296, :397-514).
 // Same structure as the 6-DoF kernel: one lane per env, SoA state read/written once per step.
 #include "mvrl_kernels.hpp"
+#if MVRL_F64
+#include "mvrl_rk45.hpp"
+#endif
 
 namespace mvrl {
 
@@ -126,9 +129,53 @@ __device__ __forceinline__ void random_init3(uint64_t seed, int64_t gid, uint32_
     toffset = u01(r1.v[1]) * t_quarter;
 }
 
-enum { R3_Y = 0, R3_EOLD = 6, R3_EINT = 9, R3_SP = 12, R3_PATH = 15, R3_TOFF = 19, R3_ISTEP = 20, R3_WORDS = 21 };
+enum { R3_Y = 0, R3_EOLD = 6, R3_EINT = 9, R3_SP = 12, R3_PATH = 15, R3_TOLD = 19, R3_TIME = 20, R3_TOFF = 21, R3_ISTEP = 22,
+       R3_WORDS = 23 };
 
-template <class PP, bool ZOH, bool FLOW>
+#if MVRL_F64
+// BlueROV2Heavy3DoF.derivs (3DoF.py:128-296) with run-time t - tOld, as the RHS functor of the adaptive solver
+template <bool FLOW, class PP>
+struct Rhs3 {
+    PP p;
+    const float* sp;
+    Pid3* pid;
+    float* told;
+    float2 cur;
+    float* aux_row;
+    __device__ void operator()(float t, const float* y, float* dy) {
+        float sn, c;
+        sincos_f32(y[2], sn, c);
+        float e[3] = {sp[0] - y[0], sp[1] - y[1], angle_error(sp[2], y[2])};
+        const float dtp = t - *told;
+        const float den = fmaxf(1e-9f, dtp);
+        float u[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float dedt = (e[i] - pid->eold[i]) / den;
+            pid->eint[i] += 0.5f * (pid->eold[i] + e[i]) * dtp;
+            pid->eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : pid->eint[i];
+            const float v = p->kp[i] * e[i] + p->kd[i] * dedt + p->ki[i] * pid->eint[i];
+            u[i] = clampf(v, -p->umax[i], p->umax[i]);
+            pid->eold[i] = e[i];
+        }
+        *told = t;
+        const float Xd = u[0] * c + u[1] * sn, Yd = -u[0] * sn + u[1] * c, Nd = u[2];
+        if (aux_row) { aux_row[0] = Xd; aux_row[1] = Yd; aux_row[2] = Nd; }
+        float F[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float cv = p->Ainv[3 * i] * Xd + p->Ainv[3 * i + 1] * Yd + p->Ainv[3 * i + 2] * Nd;
+            const float f = clampf(cv, -p->f_max, p->f_max);
+            F[i] = (fabsf(f) < p->f_dead) ? 0.f : f;
+            if (aux_row) aux_row[3 + i] = fsign(cv) * sqrtf(fabsf(cv) * p->inv_thrust_k) * 60.f;
+        }
+        dynamics3<FLOW>(p, y, c, sn, F, cur, dy);
+    }
+};
+#endif
+
+
+template <class PP, bool ZOH, bool FLOW, int INTEG>
 __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
     const uint32_t i_in = blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
@@ -143,7 +190,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     for (int k = 0; k < 6; k++) y[k] = ST(R3_Y + k);
 #pragma unroll
     for (int k = 0; k < 3; k++) { pid.eold[k] = ST(R3_EOLD + k); pid.eint[k] = ST(R3_EINT + k); }
-    int istep = __float_as_int(ST(R3_ISTEP));
+    int istep = unpack_int(ST(R3_ISTEP));
     if (io.fixed_sp) {
 #pragma unroll
         for (int k = 0; k < 3; k++) sp[k] = ST(R3_SP + k);
@@ -162,6 +209,19 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     const float h = io.dt / (float)io.n_sub, hh = 0.5f * h, h6 = h / 6.f, inv_hh = 1.0f / hh;
     float* const aux_row = io.aux ? io.aux + (size_t)i_in * 7 : nullptr;
     float inc_prev[3] = {0.f, 0.f, 0.f};  // see mvrl_rov6.hip
+#if MVRL_F64
+    if (INTEG == 1) {  // the reference's own integrator (3DoF.py:475-477), see mvrl_rk45.hpp
+        float told = ST(R3_TOLD), time = ST(R3_TIME);
+        if (first) { told = 0.f; time = 0.f; }
+        time += io.dt;
+        Rhs3<FLOW, PP> rhs{p, sp, &pid, &told, cur, aux_row};
+        int nfev = 0;
+        rk45_solve<6>(rhs, time - io.dt, time, io.dt, 1e-3, 1e-3, y, &nfev);
+        ST(R3_TOLD) = told;
+        ST(R3_TIME) = time;
+        if (io.nfev) io.nfev[i_in] = nfev;
+    } else
+#endif
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[6], acc[6], yt[6];
         float* const aux_last = (ks == io.n_sub - 1) ? aux_row : nullptr;
@@ -256,7 +316,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
 #pragma unroll
         for (int k = 0; k < 3; k++) ST(R3_SP + k) = sp[k];
     }
-    ST(R3_ISTEP) = __int_as_float(istep);
+    ST(R3_ISTEP) = pack_int(istep);
 #undef ST
 #undef LANE
 }
@@ -284,8 +344,10 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_reset_kernel(const Rov3Dev* _
     for (int q = 0; q < 3; q++) { st[(R3_EOLD + q) * n] = 0.f; st[(R3_EINT + q) * n] = 0.f; st[(R3_SP + q) * n] = sp[q]; }
 #pragma unroll
     for (int q = 0; q < 4; q++) st[(R3_PATH + q) * n] = path[q];
+    st[R3_TOLD * n] = 0.f;
+    st[R3_TIME * n] = 0.f;
     st[R3_TOFF * n] = toff;
-    st[R3_ISTEP * n] = __int_as_float(0);
+    st[R3_ISTEP * n] = pack_int(0);
     if (obs) {
         float o[5];
         observe3(p, y, path, sp, o);
@@ -295,9 +357,16 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_reset_kernel(const Rov3Dev* _
 }
 
 hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool zoh, bool flow,
-                            hipStream_t stream) {
+                            bool rk45, hipStream_t stream) {
     dim3 grid((unsigned)((io.n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
-#define MVRL_L3(PPT, Z, F) hipLaunchKernelGGL((rov3_step_kernel<PPT, Z, F>), grid, block, 0, stream, p, io, fl)
+#define MVRL_L3(PPT, Z, F) hipLaunchKernelGGL((rov3_step_kernel<PPT, Z, F, 0>), grid, block, 0, stream, p, io, fl)
+#if MVRL_F64
+    if (rk45) {
+        if (flow) hipLaunchKernelGGL((rov3_step_kernel<CP3, false, true, 1>), grid, block, 0, stream, p, io, fl);
+        else hipLaunchKernelGGL((rov3_step_kernel<CP3, false, false, 1>), grid, block, 0, stream, p, io, fl);
+        return hipGetLastError();
+    }
+#endif
     if (baked) {
         if (zoh) { if (flow) MVRL_L3(const Rov3Baked*, true, true); else MVRL_L3(const Rov3Baked*, true, false); }
         else { if (flow) MVRL_L3(const Rov3Baked*, false, true); else MVRL_L3(const Rov3Baked*, false, false); }

@@ -8,6 +8,9 @@
 // between lives in VGPRs.  The kernel is VALU-bound (~7 k lane-ops per env step against 300 B of traffic), so
 // the work here is instruction count, not bytes - see DESIGN.md.
 #include "mvrl_kernels.hpp"
+#if MVRL_F64
+#include "mvrl_rk45.hpp"
+#endif
 
 namespace mvrl {
 
@@ -318,9 +321,56 @@ __device__ __forceinline__ void random_init6(uint64_t seed, int64_t gid, uint32_
     toffset = u01(r2.v[1]) * t_quarter;
 }
 
-enum { R6_Y = 0, R6_EOLD = 12, R6_EINT = 18, R6_SP = 24, R6_PATH = 30, R6_TOFF = 36, R6_ISTEP = 37, R6_WORDS = 38 };
+// SoA planes.  TOLD/TIME (the PID's tOld and the env's accumulated time, 6DoF.py:40,534) are only touched by the
+// RK45 integrator: under the RK4 harness t - tOld is a compile-time pattern.
+enum { R6_Y = 0, R6_EOLD = 12, R6_EINT = 18, R6_SP = 24, R6_PATH = 30, R6_TOLD = 36, R6_TIME = 37, R6_TOFF = 38, R6_ISTEP = 39,
+       R6_WORDS = 40 };
 
-template <class PP, bool SYM, bool ZOH, bool FLOW>
+#if MVRL_F64
+// PID with run-time t - tOld, for the adaptive integrator (6DoF.py:43-73 verbatim)
+template <class PP>
+__device__ __forceinline__ void pid6_rt(PP p, const float* y, const float* sp, Pid6& s, float& told, float t, float* u) {
+    float e[6];
+    e[0] = sp[0] - y[0]; e[1] = sp[1] - y[1]; e[2] = sp[2] - y[2];
+    e[3] = sp[3] - y[3]; e[4] = sp[4] - y[4];
+    e[5] = angle_error(sp[5], y[5]);
+    const float dtp = t - told;
+    const float den = fmaxf(1e-9f, dtp);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float dedt = (e[i] - s.eold[i]) / den;
+        s.eint[i] += 0.5f * (s.eold[i] + e[i]) * dtp;
+        s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
+        const float v = p->kp[i] * e[i] + p->kd[i] * dedt + p->ki[i] * s.eint[i];
+        u[i] = clampf(v, -p->umax[i], p->umax[i]);
+        s.eold[i] = e[i];
+    }
+    told = t;
+}
+
+// BlueROV2Heavy6DoF.derivs as the RHS functor of the adaptive solver
+template <bool SYM, bool FLOW, class PP>
+struct Rhs6 {
+    PP p;
+    const float* sp;
+    Pid6* pid;
+    float* told;
+    float2 cur;
+    float* aux_row;  // receives the side outputs of EVERY call; the last one stays (timeHistory semantics)
+    __device__ void operator()(float t, const float* y, float* dy) {
+        Trig6 tr = trig6(y);
+        Axes ax = body_axes(tr);
+        float u[6], F[8], cv[8];
+        pid6_rt(p, y, sp, *pid, *told, t, u);
+        allocate6<SYM>(p, ax, u, F, cv);
+        if (aux_row) write_aux6(p, u, cv, aux_row);
+        dynamics6<SYM, FLOW>(p, y, tr, ax, F, cur, dy);
+    }
+};
+#endif
+
+
+template <class PP, bool SYM, bool ZOH, bool FLOW, int INTEG>
 __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
     const uint32_t i_in = blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
@@ -339,7 +389,7 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
     for (int k = 0; k < 12; k++) y[k] = ST(R6_Y + k);
 #pragma unroll
     for (int k = 0; k < 6; k++) { pid.eold[k] = ST(R6_EOLD + k); pid.eint[k] = ST(R6_EINT + k); }
-    int istep = __float_as_int(ST(R6_ISTEP));
+    int istep = unpack_int(ST(R6_ISTEP));
 
     if (io.fixed_sp) {  // 6DoF.py:536-541
 #pragma unroll
@@ -371,6 +421,20 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
     // pose increment between the last PID call of a sub-step and the first of the next; not known across env steps
     // (new set-point, angle wrap): the first call of a step uses the rounded difference (inc_valid = false)
     float inc_prev[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#if MVRL_F64
+    if (INTEG == 1) {
+        // the reference's own integrator: fresh adaptive RK45 solve over (time - dt, time)
+        float told = ST(R6_TOLD), time = ST(R6_TIME);
+        if (first) { told = 0.f; time = 0.f; }
+        time += io.dt;  // 6DoF.py:534 (accumulated, as the reference does)
+        Rhs6<SYM, FLOW, PP> rhs{p, sp, &pid, &told, cur, aux_row};
+        int nfev = 0;
+        rk45_solve<12>(rhs, time - io.dt, time, io.dt, 1e-3, 1e-3, y, &nfev);
+        ST(R6_TOLD) = told;
+        ST(R6_TIME) = time;
+        if (io.nfev) io.nfev[i_in] = nfev;
+    } else
+#endif
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[12], acc[12], yt[12];
         float* const aux_last = (ks == io.n_sub - 1) ? aux_row : nullptr;
@@ -482,7 +546,7 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
 #pragma unroll
         for (int k = 0; k < 6; k++) ST(R6_SP + k) = sp[k];
     }
-    ST(R6_ISTEP) = __int_as_float(istep);
+    ST(R6_ISTEP) = pack_int(istep);
 }
 
 // reset (6DoF.py:485-529): mask/init may be null.
@@ -512,8 +576,10 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_reset_kernel(const Rov6Dev* _
         st[(R6_EOLD + q) * n] = 0.f; st[(R6_EINT + q) * n] = 0.f;
         st[(R6_SP + q) * n] = sp[q]; st[(R6_PATH + q) * n] = path[q];
     }
+    st[R6_TOLD * n] = 0.f;
+    st[R6_TIME * n] = 0.f;
     st[R6_TOFF * n] = toff;
-    st[R6_ISTEP * n] = __int_as_float(0);
+    st[R6_ISTEP * n] = pack_int(0);
     if (obs) {
         float o[9];
         observe6(p, y, path, sp, o);
@@ -524,10 +590,19 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_reset_kernel(const Rov6Dev* _
 
 // ---- host-side launchers ---------------------------------------------------------------------------
 hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool sym, bool zoh,
-                            bool flow, hipStream_t stream) {
+                            bool flow, bool rk45, hipStream_t stream) {
     dim3 grid((unsigned)((io.n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
-#define MVRL_L6(S, Z, F) hipLaunchKernelGGL((rov6_step_kernel<CP6, S, Z, F>), grid, block, 0, stream, p, io, fl)
-#define MVRL_L6B(Z, F) hipLaunchKernelGGL((rov6_step_kernel<const Rov6Baked*, true, Z, F>), grid, block, 0, stream, p, io, fl)
+#define MVRL_L6(S, Z, F) hipLaunchKernelGGL((rov6_step_kernel<CP6, S, Z, F, 0>), grid, block, 0, stream, p, io, fl)
+#define MVRL_L6B(Z, F) hipLaunchKernelGGL((rov6_step_kernel<const Rov6Baked*, true, Z, F, 0>), grid, block, 0, stream, p, io, fl)
+#if MVRL_F64
+    if (rk45) {  // adaptive integrator: run-time constants, generic or sym arithmetic, FAITHFUL placement by definition
+        if (sym) { if (flow) hipLaunchKernelGGL((rov6_step_kernel<CP6, true, false, true, 1>), grid, block, 0, stream, p, io, fl);
+                   else hipLaunchKernelGGL((rov6_step_kernel<CP6, true, false, false, 1>), grid, block, 0, stream, p, io, fl); }
+        else { if (flow) hipLaunchKernelGGL((rov6_step_kernel<CP6, false, false, true, 1>), grid, block, 0, stream, p, io, fl);
+               else hipLaunchKernelGGL((rov6_step_kernel<CP6, false, false, false, 1>), grid, block, 0, stream, p, io, fl); }
+        return hipGetLastError();
+    }
+#endif
     if (baked) {
         if (zoh) { if (flow) MVRL_L6B(true, true); else MVRL_L6B(true, false); }
         else { if (flow) MVRL_L6B(false, true); else MVRL_L6B(false, false); }

@@ -18,7 +18,9 @@ ABI_VERSION = 1
 
 MODEL_NAMES = {"auv": MODEL_AUV, "rov3": MODEL_ROV3, "rov6": MODEL_ROV6}
 #            act, obs, init, state_words, aux
-MODEL_DIMS = {MODEL_AUV: (3, 11, 16, 53, 11), MODEL_ROV3: (3, 5, 5, 21, 7), MODEL_ROV6: (6, 9, 9, 38, 14)}
+MODEL_DIMS = {MODEL_AUV: (3, 11, 16, 53, 11), MODEL_ROV3: (3, 5, 5, 23, 7), MODEL_ROV6: (6, 9, 9, 40, 14)}
+PREC_F32, PREC_F64 = 0, 1
+INTEG_RK4, INTEG_RK45 = 0, 1
 
 d = C.c_double
 
@@ -56,7 +58,8 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("model", C.c_int32), ("device", C.c_int32), ("n_substeps", C.c_int32),
                 ("n_envs", C.c_int64), ("env_offset", C.c_int64), ("dt", d), ("max_steps", C.c_int32),
                 ("control_mode", C.c_int32), ("fixed_setpoint", C.c_int32), ("auto_reset", C.c_int32),
-                ("seed", C.c_uint64), ("use_flow", C.c_int32), ("_pad", C.c_int32),
+                ("seed", C.c_uint64), ("use_flow", C.c_int32), ("precision", C.c_int32), ("integrator", C.c_int32),
+                ("_pad", C.c_int32),
                 ("rov6", Rov6Params), ("rov3", Rov3Params), ("auv", AuvParams)]
 
 
@@ -217,7 +220,7 @@ def auv_params(noiseMagCoeffs=0.0, noiseMagActuation=0.0, stopOnBoundsExceeded=T
 
 def make_config(model, n_envs, *, dt=None, n_substeps=4, max_steps=250, control_mode=CTRL_FAITHFUL,
                 fixed_setpoint=False, auto_reset=True, seed=0, use_flow=None, device=0, env_offset=0,
-                rov6=None, rov3=None, auv=None):
+                rov6=None, rov3=None, auv=None, precision="f32", integrator="rk4"):
     if isinstance(model, str):
         model = MODEL_NAMES[model]
     cfg = Config()
@@ -234,6 +237,8 @@ def make_config(model, n_envs, *, dt=None, n_substeps=4, max_steps=250, control_
     cfg.auto_reset = 1 if auto_reset else 0
     cfg.seed = seed
     cfg.use_flow = int(model == MODEL_AUV) if use_flow is None else int(bool(use_flow))
+    cfg.precision = {"f32": PREC_F32, "f64": PREC_F64}[precision] if isinstance(precision, str) else int(precision)
+    cfg.integrator = {"rk4": INTEG_RK4, "rk45": INTEG_RK45}[integrator] if isinstance(integrator, str) else int(integrator)
     cfg.rov6 = rov6 if rov6 is not None else rov6_params()
     cfg.rov3 = rov3 if rov3 is not None else rov3_params()
     cfg.auv = auv if auv is not None else auv_params()
