@@ -58,7 +58,11 @@ def build_lib(force=False, verbose=False, extra_flags=None, out=None, drop_flags
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
         if force or _stale(o, [s] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            flags = list(FLAGS)
+            if src.startswith("gen/"):
+                # the fp64 twins are the exactness path: IEEE arithmetic, no contraction beyond the explicit fma() calls
+                flags = [f for f in flags if f != "-ffast-math"] + ["-ffp-contract=off"]
+            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

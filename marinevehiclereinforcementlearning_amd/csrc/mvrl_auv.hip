@@ -63,7 +63,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     if (i >= (uint32_t)io.n) return;
     const uint32_t n32 = (uint32_t)io.n;
     char* const stb = reinterpret_cast<char*>(io.state);
-#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) << 2)))
+#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) * (uint32_t)sizeof(float))))
     float x = ST(AV_X), y = ST(AV_Y), psi = ST(AV_PSI), vx = ST(AV_VX), vy = ST(AV_VY), r = ST(AV_R);
     const float tgt = ST(AV_TGT);
     float herr_o = ST(AV_HERR_O), perr_ox = ST(AV_PERR_O), perr_oy = ST(AV_PERR_O + 1);

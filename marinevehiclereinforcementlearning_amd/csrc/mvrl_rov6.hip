@@ -380,7 +380,7 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
     // instead of a 64-bit VGPR address pair per plane.  The host guarantees words * n < 2^30.
     const uint32_t n32 = (uint32_t)io.n;
     char* const stb = reinterpret_cast<char*>(io.state);
-#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) << 2)))
+#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) * (uint32_t)sizeof(float))))
 #define LANE i_in
 
     float y[12], sp[6], path[6];

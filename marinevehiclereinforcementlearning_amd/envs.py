@@ -24,7 +24,12 @@ class _RovEnvBase(object):
     _DOF = 6
 
     def __init__(self, seed=None, dt=0.2, maxSteps=250, n_substeps=4, control_mode="faithful", device=0,
-                 vehicle_params=None):
+                 vehicle_params=None, integrator="rk4", precision=None):
+        """seed, dt, maxSteps: the reference's arguments (6DoF.py:446 / 3DoF.py:376).  integrator="rk45" (implies
+        precision="f64") selects the reference's own adaptive solve_ivp(RK45) and reproduces its env.step
+        trajectories; the default is this build's fixed-step RK4 in fp32."""
+        self._integ = integrator
+        self._prec = precision or ("f64" if integrator == "rk45" else "f32")
         self.seed = seed
         self.dt = dt
         self._max_episode_steps = maxSteps
@@ -51,7 +56,8 @@ class _RovEnvBase(object):
                 kw["rov6" if self._DOF == 6 else "rov3"] = self._vp
             cfg = P.make_config("rov6" if self._DOF == 6 else "rov3", 1, dt=self.dt, n_substeps=self._n_sub,
                                 max_steps=self._max_episode_steps, control_mode=self._cm, fixed_setpoint=fixed,
-                                auto_reset=False, use_flow=False, device=self._device, **kw)
+                                auto_reset=False, use_flow=False, device=self._device, precision=self._prec,
+                                integrator=self._integ, **kw)
             self._h = _lib.Handle(cfg)
             self._h.enable_aux(True)
             self._fixed = fixed
@@ -97,7 +103,7 @@ class _RovEnvBase(object):
         if dof == 6:
             self.vehicle.controller = _Namespace()
         h = self._handle(self.fixedSp)
-        init = np.concatenate([self.path.ravel(), target])[None].astype(np.float32)
+        init = np.concatenate([self.path.ravel(), target])[None]
         obs = h.reset(init=init)[0].astype(np.float64)
         self._pull()
         self.vehicle.generalisedControlForces = np.zeros(dof)
@@ -127,7 +133,7 @@ class _RovEnvBase(object):
     def step(self, action):
         self.iStep += 1
         self.time += self.dt
-        a = np.asarray(action, dtype=np.float32).reshape(1, self._DOF)
+        a = np.asarray(action, dtype=np.float64).reshape(1, self._DOF)
         obs, rew, done = self._h.step(a)
         self._pull()
         self.state = obs[0].astype(np.float64)

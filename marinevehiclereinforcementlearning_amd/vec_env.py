@@ -65,7 +65,7 @@ class MarineVecEnv:
     def __init__(self, model, num_envs, *, seed=0, dt=None, maxSteps=250, n_substeps=4, control_mode="faithful",
                  fixed_setpoint=False, flow=None, currentVelScale=1.0, currentTurbScale=2.0, noiseMagCoeffs=0.0,
                  noiseMagActuation=0.0, stopOnBoundsExceeded=True, device=0, env_offset=0, infos="dict",
-                 vehicle_params=None):
+                 vehicle_params=None, precision="f32", integrator="rk4"):
         self.model = P.MODEL_NAMES[model] if isinstance(model, str) else int(model)
         self.model_name = {v: k for k, v in P.MODEL_NAMES.items()}[self.model]
         self.num_envs = int(num_envs)
@@ -84,7 +84,8 @@ class MarineVecEnv:
             kw["rov6" if self.model == P.MODEL_ROV6 else "rov3"] = vehicle_params
         self.cfg = P.make_config(self.model, self.num_envs, dt=dt, n_substeps=n_substeps, max_steps=maxSteps,
                                  control_mode=cm, fixed_setpoint=fixed_setpoint, auto_reset=True, seed=seed or 0,
-                                 use_flow=use_flow, device=device, env_offset=env_offset, **kw)
+                                 use_flow=use_flow, device=device, env_offset=env_offset, precision=precision,
+                                 integrator=integrator, **kw)
         self.dt = self.cfg.dt
         self._h = _lib.Handle(self.cfg)
         self.flow = flow
@@ -102,11 +103,15 @@ class MarineVecEnv:
         return self._h.reset(init=init).copy()
 
     def step_async(self, actions):
-        self._h.step_async(actions)  # not clipped here: the reference envs apply the raw action (6DoF.py:545-551)
+        # not clipped here: the reference envs apply the raw action (6DoF.py:545-551)
+        if self._h.f64:
+            self._deferred = actions          # fp64 handles step synchronously in step_wait
+        else:
+            self._h.step_async(actions)
         self._pending = True
 
     def step_wait(self):
-        obs, rew, done = self._h.step_wait()
+        obs, rew, done = self._h.step(self._deferred) if self._h.f64 else self._h.step_wait()
         self._pending = False
         bits = done.copy()
         dones = bits != 0
@@ -175,8 +180,9 @@ class MarineVecEnv:
             import torch
             dev = torch.device("cuda", self.cfg.device)
             n = self.num_envs
-            self._tensors = (torch.empty((n, self.observation_space.shape[0]), dtype=torch.float32, device=dev),
-                             torch.empty((n,), dtype=torch.float32, device=dev),
+            rt = torch.float64 if self._h.f64 else torch.float32
+            self._tensors = (torch.empty((n, self.observation_space.shape[0]), dtype=rt, device=dev),
+                             torch.empty((n,), dtype=rt, device=dev),
                              torch.empty((n,), dtype=torch.uint8, device=dev))
         return self._tensors
 
@@ -191,7 +197,8 @@ class MarineVecEnv:
         (obs, reward, done_bits) tensors that are overwritten by the next call.  Enqueued on torch's current stream;
         nothing crosses PCIe."""
         import torch
-        assert actions.is_cuda and actions.dtype == torch.float32 and actions.is_contiguous()
+        assert actions.is_cuda and actions.is_contiguous()
+        assert actions.dtype == (torch.float64 if self._h.f64 else torch.float32)
         obs, rew, done = self._ensure_tensors()
         self._h.step_dev(actions.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
                          torch.cuda.current_stream().cuda_stream)

@@ -159,3 +159,22 @@ def test_reconstructed_flow_mirror():
     modes, coeffs = synthetic_spod(2, 4)
     with pytest.raises(ValueError, match="Non-uniform"):
         ReconstructedFlow(modes=modes, coeffs=coeffs, lt_mean=np.load(os.path.join(GOLDEN, "ltm.npy")), coords=bad)
+
+
+def test_gym_facade_rk45_reproduces_reference_env_step():
+    """BlueROV2Heavy6DoFEnv(integrator="rk45"): the drop-in for the reference's real env.step (golden g10, generated
+    by the reference's own BlueROV2Heavy6DoFEnv.reset(initialSetpoint=sp) + step loop)."""
+    g = golden("g10_envstep_6dof_fixedsp.npz")
+    env = BlueROV2Heavy6DoFEnv(maxSteps=250, integrator="rk45")
+    env.reset(initialSetpoint=g["sp0"][0])
+    for s in range(40):
+        obs, reward, done, _ = env.step(np.zeros(6))
+        assert max_scaled_err(env.systemState, g["states"][0, s + 1]) < 1e-6, s
+        assert max_scaled_err(env.vehicle.controlVector / 3500., g["rpm"][0, s] / 3500.) < 1e-4
+    vec = MarineVecEnv("rov3", 8, seed=2, precision="f64", integrator="rk45", maxSteps=3)
+    o = vec.reset()
+    assert o.dtype == np.float64
+    for _ in range(3):
+        o, r, d, infos = vec.step(np.zeros((8, 3)))
+    assert d.all() and infos[0]["TimeLimit.truncated"]
+    env.close(); vec.close()
