@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--gather", default="root", choices=["root", "all", "none"])
     ap.add_argument("--n-substeps", type=int, default=4)
     ap.add_argument("--control-mode", default="faithful", choices=["faithful", "zoh"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="f64 = the exactness build of the same kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=12345)
     args = ap.parse_args()
@@ -130,13 +131,16 @@ def main():
             flow_np = dict(table=flow.table_uv().astype(np.float64), dt=flow.dt, dx=flow.dx, dy=flow.dy)
 
     env = MarineVecEnv(wl["model"], n, seed=args.seed, n_substeps=args.n_substeps, control_mode=args.control_mode,
-                       flow=flow, device=local_rank, env_offset=rank * n, infos="lean")
+                       flow=flow, device=local_rank, env_offset=rank * n, infos="lean", precision=args.precision)
     act_dim, obs_dim = env.action_space.shape[0], env.observation_space.shape[0]
     h = env.handle
     stream = torch.cuda.current_stream().cuda_stream
     ring = torch.empty((RING, n, act_dim), dtype=torch.float32, device=dev)
     for r in range(RING):
         h.fill_uniform_dev(ring[r].data_ptr(), n * act_dim, args.seed, rank * RING + r, -1.0, 1.0, stream)
+    if args.precision == "f64":
+        ring = ring.double()
+        wl["bytes"] *= 2  # every word of state / action / observation is 8 bytes wide
     env.reset_tensors()
 
     def sync():
@@ -222,7 +226,7 @@ def main():
         out = {
             "metric": "env-steps/sec (whole node) + achieved HBM GB/s, 6-DoF batch", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": wl["name"], "envs_per_gpu": n, "global_envs": world * n, "dt": 0.2 if wl["model"] != "auv" else 0.02,
                        "n_substeps": args.n_substeps, "control_mode": args.control_mode, "episode_len": 250,
                        "kernel": env.variant, "actions": f"ring of {RING} pre-generated uniform(-1,1) batches in HBM"},
