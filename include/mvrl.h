@@ -110,7 +110,8 @@ typedef struct mvrl_rov3_params {
     double obs_pos_scale, obs_ang_scale;
 } mvrl_rov3_params;
 
-/* Simplified AUV - tag/verySimpleAuv.py:106-127 */
+#define MVRL_MAX_WAYPOINTS 32
+/* Simplified AUV - tag/verySimpleAuv.py:106-127 ; its way-point variant AuvEnvCyl - tag/verySimpleAuv_cyl.py:22-344 */
 typedef struct mvrl_auv_params {
     double m, izz;
     double xuu, yvv, nrr, xu, yv, nr;
@@ -118,7 +119,13 @@ typedef struct mvrl_auv_params {
     double x_min, x_max, y_min, y_max;   /* :106-107 */
     double noise_mag_coeffs, noise_mag_actuation; /* :124-125 */
     int32_t stop_on_bounds;              /* :88 */
-    int32_t _pad;
+    int32_t n_waypoints;                 /* 0: AuvEnv (target = origin, random target heading).  > 0: AuvEnvCyl - the target
+                                            follows waypoints[iWp] and advances when closer than wp_threshold
+                                            (tag/verySimpleAuv_cyl.py:30-40, :249-253) */
+    double obs_scale[9];                 /* observation = clip(raw * scale): all 1 except herr/(45 deg) for AuvEnv "V3"
+                                            (verySimpleAuv.py:201-212); the "V0" scaling of AuvEnvCyl (_cyl.py:100-111) */
+    double wp_threshold;                 /* Rcyl * 0.05 */
+    double waypoints[3 * MVRL_MAX_WAYPOINTS]; /* x, y, target heading per way-point */
 } mvrl_auv_params;
 
 /* Turbulence table as produced by ReconstructedFlow.scale (tag/flowGenerator.py:53-95):
@@ -186,7 +193,8 @@ int mvrl_set_flow_dev(mvrl_handle* h, const void* table_dev, const mvrl_flow_des
  *        ROV6: wp0(3) wp1(3) target angles(3)   (reset(initialSetpoint=sp) == wp0=wp1=sp[:3], angles=sp[3:])
  *        ROV3: wp0(2) wp1(2) target heading(1)
  *        AUV : x y heading headingTarget flowTimeOffset  mMult IMult XuuMult YvvMult NrrMult XuMult YvMult NrMult
- *              XactMult YactMult NactMult   (fixedInitialValues + the multipliers of verySimpleAuv.py:222-229,245)
+ *              XactMult YactMult NactMult   (fixedInitialValues + the multipliers of verySimpleAuv.py:222-229,245);
+ *              with way-points (AuvEnvCyl) slot 3 carries the way-point index iWp instead of the target heading
  * obs  : [n_envs, obs_dim] out (rows of envs that were not reset are left untouched); may be NULL. */
 int mvrl_reset(mvrl_handle* h, const uint8_t* mask, const float* init, float* obs);
 int mvrl_reset_f64(mvrl_handle* h, const uint8_t* mask, const double* init, double* obs);

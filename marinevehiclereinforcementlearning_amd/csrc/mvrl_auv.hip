@@ -12,25 +12,35 @@ namespace mvrl {
 enum {
     AV_X = 0, AV_Y = 1, AV_PSI = 2, AV_VX = 3, AV_VY = 4, AV_R = 5, AV_TGT = 6, AV_HERR_O = 7, AV_PERR_O = 8,
     AV_MULT = 10,   // m I Xuu Yvv Nrr Xu Yv Nr Xact Yact Nact  (verySimpleAuv.py:222-229)
-    AV_TOFF = 21, AV_HIST = 22, AV_ISTEP = 52, AV_WORDS = 53
+    AV_TOFF = 21, AV_HIST = 22, AV_ISTEP = 52,
+    AV_IWP = 53,    // AuvEnvCyl: way-point index (integer bit pattern); survives reset() like the reference's self.iWp
+    AV_WORDS = 54
 };
 
 // dataToState "V3" (verySimpleAuv.py:201-212); positionTarget = 0 (:241)
-__device__ __forceinline__ void observe_auv(float x, float y, float psi, float vx, float vy, float r, float tgt,
-                                            float herr_o, float perr_ox, float perr_oy, float* o) {
-    float perr0 = 0.f - x, perr1 = 0.f - y;
+// obs_scale: all ones except 1/(45 deg) on the heading error for AuvEnv's "V3"; AuvEnvCyl's "V0" scaling otherwise
+// (tag/verySimpleAuv_cyl.py:100-111)
+__device__ __forceinline__ void observe_auv(const AuvDev& p, float x, float y, float psi, float vx, float vy, float r,
+                                            float tx, float ty, float tgt, float herr_o, float perr_ox, float perr_oy,
+                                            float* o) {
+    float perr0 = tx - x, perr1 = ty - y;
     float herr = angle_error(tgt, psi);
-    o[0] = clampf(perr0, -1.f, 1.f);
-    o[1] = clampf(perr1, -1.f, 1.f);
-    o[2] = clampf(herr * (1.0f / 0.78539816339744830962f), -1.f, 1.f);
-    o[3] = clampf(herr - herr_o, -1.f, 1.f);
-    o[4] = clampf(perr0 - perr_ox, -1.f, 1.f);
-    o[5] = clampf(perr1 - perr_oy, -1.f, 1.f);
-    o[6] = clampf(vx, -1.f, 1.f);
-    o[7] = clampf(vy, -1.f, 1.f);
-    o[8] = clampf(r, -1.f, 1.f);
+    o[0] = clampf(perr0 * p.obs_scale[0], -1.f, 1.f);
+    o[1] = clampf(perr1 * p.obs_scale[1], -1.f, 1.f);
+    o[2] = clampf(herr * p.obs_scale[2], -1.f, 1.f);
+    o[3] = clampf((herr - herr_o) * p.obs_scale[3], -1.f, 1.f);
+    o[4] = clampf((perr0 - perr_ox) * p.obs_scale[4], -1.f, 1.f);
+    o[5] = clampf((perr1 - perr_oy) * p.obs_scale[5], -1.f, 1.f);
+    o[6] = clampf(vx * p.obs_scale[6], -1.f, 1.f);
+    o[7] = clampf(vy * p.obs_scale[7], -1.f, 1.f);
+    o[8] = clampf(r * p.obs_scale[8], -1.f, 1.f);
     o[9] = 0.f;
     o[10] = 0.f;
+}
+
+// positionTarget / headingTarget of way-point k (verySimpleAuv_cyl.py:141-142)
+__device__ __forceinline__ void waypoint(const AuvDev& p, int k, float& tx, float& ty, float& th) {
+    tx = p.wp[3 * k]; ty = p.wp[3 * k + 1]; th = p.wp[3 * k + 2];
 }
 
 // reset draws (verySimpleAuv.py:222-245), order: 8 coefficient multipliers, 3 actuation multipliers,
@@ -65,7 +75,10 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     char* const stb = reinterpret_cast<char*>(io.state);
 #define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) * (uint32_t)sizeof(float))))
     float x = ST(AV_X), y = ST(AV_Y), psi = ST(AV_PSI), vx = ST(AV_VX), vy = ST(AV_VY), r = ST(AV_R);
-    const float tgt = ST(AV_TGT);
+    float tgt = ST(AV_TGT), tx = 0.f, ty = 0.f;   // positionTarget = 0 for AuvEnv (verySimpleAuv.py:241)
+    int iwp = 0;
+    const bool cyl = p.n_wp > 0;
+    if (cyl) { iwp = unpack_int(ST(AV_IWP)); waypoint(p, iwp, tx, ty, tgt); }
     float herr_o = ST(AV_HERR_O), perr_ox = ST(AV_PERR_O), perr_oy = ST(AV_PERR_O + 1);
     float mu[11];
 #pragma unroll
@@ -110,12 +123,16 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     vx = fmaf(acc0, h, vx); vy = fmaf(acc1, h, vy); r = fmaf(acc2, h, r);
 
     float o[11];
-    observe_auv(x, y, psi, vx, vy, r, tgt, herr_o, perr_ox, perr_oy, o);               // :329
+    observe_auv(p, x, y, psi, vx, vy, r, tx, ty, tgt, herr_o, perr_ox, perr_oy, o);    // :329
     float bonus = 0.f;                                                                  // :335-342
     if (x < p.x_min || x > p.x_max) { if (p.stop_on_bounds) done = true; bonus += -100.f; }
     if (y < p.y_min || y > p.y_max) { if (p.stop_on_bounds) done = true; bonus += -100.f; }
-    const float perr0 = 0.f - x, perr1 = 0.f - y;
+    const float perr0 = tx - x, perr1 = ty - y;
     const float herr = angle_error(tgt, psi);
+    if (cyl && sqrtf(perr0 * perr0 + perr1 * perr1) < p.wp_thr) {                       // _cyl.py:249-253
+        iwp = min(p.n_wp - 1, iwp + 1);
+        waypoint(p, iwp, tx, ty, tgt);
+    }
     herr_o = herr; perr_ox = perr0; perr_oy = perr1;                                    // :349-350
     float rms = 0.f;                                                                    // :353-355
     const float inv_nh = 1.0f / (float)nh;
@@ -152,13 +169,13 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
         float v[16];
         random_init_auv(p, io.seed, io.env_offset + (int64_t)i, io.epoch, fl.t_quarter, v);
         x = v[0]; y = v[1]; psi = v[2]; vx = 0.f; vy = 0.f; r = 0.f;
-        ST(AV_TGT) = v[3];
+        if (!cyl) tgt = v[3];   // AuvEnvCyl: the target stays waypoints[iWp] - iWp is not reset (_cyl.py:41,141-142)
         ST(AV_TOFF) = v[4];
 #pragma unroll
         for (int q = 0; q < 11; q++) ST(AV_MULT + q) = v[5 + q];
-        perr_ox = 0.f - x; perr_oy = 0.f - y; herr_o = angle_error(v[3], psi);         // herr_o = None -> first call (:160-162)
+        perr_ox = tx - x; perr_oy = ty - y; herr_o = angle_error(tgt, psi);            // herr_o = None -> first call (:160-162)
         istep = 0;
-        observe_auv(x, y, psi, vx, vy, r, v[3], herr_o, perr_ox, perr_oy, o);
+        observe_auv(p, x, y, psi, vx, vy, r, tx, ty, tgt, herr_o, perr_ox, perr_oy, o);
     } else {
         // only the ring slot that changed is written back
 #pragma unroll
@@ -168,6 +185,8 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     for (int q = 0; q < 11; q++) io.obs[(size_t)i * 11 + q] = o[q];
     ST(AV_X) = x; ST(AV_Y) = y; ST(AV_PSI) = psi; ST(AV_VX) = vx; ST(AV_VY) = vy; ST(AV_R) = r;
     ST(AV_HERR_O) = herr_o; ST(AV_PERR_O) = perr_ox; ST(AV_PERR_O + 1) = perr_oy;
+    if (cyl || (done && io.auto_reset)) ST(AV_TGT) = tgt;   // the target only changes on way-point switches / new episodes
+    if (cyl) ST(AV_IWP) = pack_int(iwp);
     ST(AV_ISTEP) = pack_int(istep);
 #undef ST
 }
@@ -186,11 +205,19 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_reset_kernel(const AuvDev p, f
     } else {
         random_init_auv(p, seed, env_offset + i, epoch, t_quarter, v);
     }
-    const float x = v[0], y = v[1], psi = v[2], tgt = v[3];
+    const float x = v[0], y = v[1], psi = v[2];
+    float tgt = v[3], tx = 0.f, ty = 0.f;
+    if (p.n_wp > 0) {
+        // explicit initial values carry iWp in slot 3; a random reset keeps the env's current iWp (_cyl.py:41)
+        int iwp = init ? max(0, min(p.n_wp - 1, (int)v[3])) : unpack_int(st[AV_IWP * n]);
+        iwp = max(0, min(p.n_wp - 1, iwp));
+        st[AV_IWP * n] = pack_int(iwp);
+        waypoint(p, iwp, tx, ty, tgt);
+    }
     st[AV_X * n] = x; st[AV_Y * n] = y; st[AV_PSI * n] = psi;
     st[AV_VX * n] = 0.f; st[AV_VY * n] = 0.f; st[AV_R * n] = 0.f;
     st[AV_TGT * n] = tgt;
-    const float herr_o = angle_error(tgt, psi), perr_ox = 0.f - x, perr_oy = 0.f - y;
+    const float herr_o = angle_error(tgt, psi), perr_ox = tx - x, perr_oy = ty - y;
     st[AV_HERR_O * n] = herr_o; st[AV_PERR_O * n] = perr_ox; st[(AV_PERR_O + 1) * n] = perr_oy;
 #pragma unroll
     for (int q = 0; q < 11; q++) st[(AV_MULT + q) * n] = v[5 + q];
@@ -200,7 +227,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_reset_kernel(const AuvDev p, f
     st[AV_ISTEP * n] = pack_int(0);
     if (obs) {
         float o[11];
-        observe_auv(x, y, psi, 0.f, 0.f, 0.f, tgt, herr_o, perr_ox, perr_oy, o);
+        observe_auv(p, x, y, psi, 0.f, 0.f, 0.f, tx, ty, tgt, herr_o, perr_ox, perr_oy, o);
 #pragma unroll
         for (int q = 0; q < 11; q++) obs[i * 11 + q] = o[q];
     }

@@ -208,6 +208,10 @@ struct AuvDev {
     float x_min, x_max, y_min, y_max;
     float noise_coeffs, noise_act;
     int stop_on_bounds;
+    int n_wp;               // > 0: AuvEnvCyl way-point following
+    float obs_scale[9];
+    float wp_thr;
+    float wp[96];           // x, y, target heading per way-point
 };
 
 // Model constants are read through a CONSTANT-address-space pointer so that they come in through the scalar

@@ -27,6 +27,6 @@ hipError_t launch_flow_reconstruct(const float* modes_re, const float* modes_im,
 hipError_t launch_fill_uniform(float* dst, int64_t n, uint64_t seed, uint64_t counter, float lo, float hi,
                                hipStream_t stream);
 
-enum { R6_WORDS_ = 40, R3_WORDS_ = 23, AUV_WORDS_ = 53 };
+enum { R6_WORDS_ = 40, R3_WORDS_ = 23, AUV_WORDS_ = 54 };
 
 }  // namespace mvrl

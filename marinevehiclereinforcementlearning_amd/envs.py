@@ -176,12 +176,14 @@ class BlueROV2Heavy3DoFEnv(_RovEnvBase):
 class AuvEnv(object):
     """tag/verySimpleAuv.py:76-416.  `flow` may be a ready ReconstructedFlow; by default the constructor loads
     "./turbulenceData" like the reference (verySimpleAuv.py:102-104)."""
+    _CYL = False
+    _MAX_STEPS = 250
 
     def __init__(self, seed=None, dt=0.02, noiseMagCoeffs=0.0, noiseMagActuation=0.0, currentVelScale=1.0,
                  currentTurbScale=2.0, stopOnBoundsExceeded=True, flow=None, device=0):
         from .flow import ReconstructedFlow
         self.seed = seed
-        self._max_episode_steps = 250
+        self._max_episode_steps = self._MAX_STEPS
         self.stopOnBoundsExceeded = stopOnBoundsExceeded
         self.iStep = 0
         self.dt = dt
@@ -190,8 +192,13 @@ class AuvEnv(object):
         self.flow = flow if flow is not None else ReconstructedFlow("./turbulenceData", device=device)
         self.flow.scale(11., currentVelScale, currentTurbScale, translate=(-1.65, -1.1))
         self.timeHistory = []
-        self.xMinMax = [-1, 1]
-        self.yMinMax = [-1, 1]
+        self.xMinMax = [-2, 2] if self._CYL else [-1, 1]
+        self.yMinMax = [-2, 2] if self._CYL else [-1, 1]
+        if self._CYL:                                   # verySimpleAuv_cyl.py:29-41
+            self.Rcyl = 1.33
+            self.xCyl = np.array([2.5, 0.])
+            self.waypoints, self.wpThreshold = P.cylinder_waypoints(self.Rcyl, self.xCyl)
+            self.iWp = 0
         self.m, self.Izz = 11.4, 0.16
         self.Xuu, self.Yvv, self.Nrr = -18.18 * 2.21, -21.66 * 4.87, -1.55
         self.Xu, self.Yv, self.Nr = -4.03 * 2.21, -6.22 * 4.87, -0.07
@@ -202,7 +209,8 @@ class AuvEnv(object):
         self.action_space = unit_box(3)
         self.observation_space = unit_box(11)
         cfg = P.make_config("auv", 1, dt=dt, max_steps=self._max_episode_steps, auto_reset=False, use_flow=True,
-                            device=device, auv=P.auv_params(noiseMagCoeffs, noiseMagActuation, stopOnBoundsExceeded))
+                            device=device, auv=P.auv_params(noiseMagCoeffs, noiseMagActuation, stopOnBoundsExceeded,
+                                                            cyl=self._CYL))
         self._h = _lib.Handle(cfg)
         self._h.set_flow(self.flow.table_uv(), self.flow.dt, self.flow.dx, self.flow.dy)
         self._h.enable_aux(True)
@@ -219,12 +227,19 @@ class AuvEnv(object):
         st[6, 0] = self.headingTarget
         st[10:21, 0] = [getattr(self, k) for k in self._MULT]
         st[21, 0] = self.flowDataTimeOffset
+        if self._CYL:
+            st[53:54, 0].view(np.int32)[0] = int(self.iWp)
         self._h.set_state(st)
 
     def _pull(self):
         st = self._h.get_state()[:, 0].astype(np.float64)
         self.position, self.heading, self.velocities = st[0:2].copy(), float(st[2]), st[3:6].copy()
         self.herr_o, self.perr_o = float(st[7]), st[8:10].copy()
+        if self._CYL:
+            raw = self._h.get_state()
+            object.__setattr__(self, "iWp", int(raw[53:54, 0].view(np.int32)[0]))
+            object.__setattr__(self, "positionTarget", self.waypoints[self.iWp, :2])
+            object.__setattr__(self, "headingTarget", float(self.waypoints[self.iWp, 2]))
 
     def reset(self, keepTimeHistory=False, applyNoise=True, fixedInitialValues=None):
         # draw order and formulas of verySimpleAuv.py:222-245, from the global numpy generator like the reference
@@ -239,13 +254,19 @@ class AuvEnv(object):
             self.position = (np.random.rand(2) - 0.5) * 0.5 * np.array([self.xMinMax[1] - self.xMinMax[0],
                                                                         self.yMinMax[1] - self.yMinMax[0]])
             self.heading = np.random.rand() * 2. * np.pi
-            self.headingTarget = np.random.rand() * 2. * np.pi
+            if not self._CYL:
+                self.headingTarget = np.random.rand() * 2. * np.pi
         else:
             self.position = np.array(fixedInitialValues[0], dtype=np.float64)
             self.heading = float(fixedInitialValues[1])
-            self.headingTarget = float(fixedInitialValues[2])
+            if not self._CYL:
+                self.headingTarget = float(fixedInitialValues[2])
         self.positionStart = self.position.copy()
-        self.positionTarget = np.zeros(2)
+        if self._CYL:   # the target follows the way-point list; iWp is NOT reset (verySimpleAuv_cyl.py:41,141-142)
+            self.positionTarget = self.waypoints[self.iWp, :2]
+            self.headingTarget = float(self.waypoints[self.iWp, 2])
+        else:
+            self.positionTarget = np.zeros(2)
         self.headingStart = self.heading
         self.flowDataTimeOffset = np.random.rand() * self.flow.time[self.flow.time.shape[0] // 4]
         self.velocities = np.zeros(3)
@@ -253,7 +274,8 @@ class AuvEnv(object):
         self.iStep = 0
         self.steps_beyond_done = 0
         self.timeHistory = []
-        init = np.concatenate([self.position, [self.heading, self.headingTarget, self.flowDataTimeOffset], mult])
+        slot3 = float(self.iWp) if self._CYL else self.headingTarget
+        init = np.concatenate([self.position, [self.heading, slot3, self.flowDataTimeOffset], mult])
         self.state = self._h.reset(init=init[None].astype(np.float32))[0].astype(np.float64)
         self._pull()
         self._dirty = False
@@ -261,7 +283,7 @@ class AuvEnv(object):
 
     def __setattr__(self, k, v):
         object.__setattr__(self, k, v)
-        if k in AuvEnv._MULT or k in ("flowDataTimeOffset", "headingTarget"):
+        if k in AuvEnv._MULT or k in ("flowDataTimeOffset", "headingTarget", "iWp"):
             object.__setattr__(self, "_dirty", True)
 
     def dataToState(self, pos, heading, velocities):
@@ -312,6 +334,13 @@ class AuvEnv(object):
         if self._h is not None:
             self._h.close()
             self._h = None
+
+
+class AuvEnvCyl(AuvEnv):
+    """tag/verySimpleAuv_cyl.py:22-344 - AuvEnv following 21 way-points round a cylinder: 1200-step episodes, +-2 m
+    bounds, the scaled "V0" observation, target switching inside step()."""
+    _CYL = True
+    _MAX_STEPS = 1200
 
 
 def make_env(rank, seed=0, env_kwargs={}):

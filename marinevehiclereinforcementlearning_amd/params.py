@@ -18,7 +18,8 @@ ABI_VERSION = 1
 
 MODEL_NAMES = {"auv": MODEL_AUV, "rov3": MODEL_ROV3, "rov6": MODEL_ROV6}
 #            act, obs, init, state_words, aux
-MODEL_DIMS = {MODEL_AUV: (3, 11, 16, 53, 11), MODEL_ROV3: (3, 5, 5, 23, 7), MODEL_ROV6: (6, 9, 9, 40, 14)}
+MAX_WAYPOINTS = 32
+MODEL_DIMS = {MODEL_AUV: (3, 11, 16, 54, 11), MODEL_ROV3: (3, 5, 5, 23, 7), MODEL_ROV6: (6, 9, 9, 40, 14)}
 PREC_F32, PREC_F64 = 0, 1
 INTEG_RK4, INTEG_RK45 = 0, 1
 
@@ -46,7 +47,7 @@ class AuvParams(C.Structure):
     _fields_ = [("m", d), ("izz", d), ("xuu", d), ("yvv", d), ("nrr", d), ("xu", d), ("yv", d), ("nr", d),
                 ("max_force", d), ("max_moment", d), ("x_min", d), ("x_max", d), ("y_min", d), ("y_max", d),
                 ("noise_mag_coeffs", d), ("noise_mag_actuation", d), ("stop_on_bounds", C.c_int32),
-                ("_pad", C.c_int32)]
+                ("n_waypoints", C.c_int32), ("obs_scale", d * 9), ("wp_threshold", d), ("waypoints", d * (3 * 32))]
 
 
 class FlowDesc(C.Structure):
@@ -203,10 +204,32 @@ def rov3_params(**overrides):
     return p
 
 
+def cylinder_waypoints(Rcyl=1.33, xCyl=(2.5, 0.)):
+    """The 21 way-points round the cylinder (tag/verySimpleAuv_cyl.py:29-40): [x, y, target heading]."""
+    Rwp = Rcyl * 1.3
+    t = np.linspace(-30, 30, 21) * np.pi / 180.
+    x = -Rwp * np.cos(t) + xCyl[0]
+    y = Rwp * np.sin(t) + xCyl[1]
+    return np.vstack([x, y, -t]).T, Rcyl * 0.05
+
+
 def auv_params(noiseMagCoeffs=0.0, noiseMagActuation=0.0, stopOnBoundsExceeded=True,
-               xMinMax=(-1., 1.), yMinMax=(-1., 1.)):
-    """AuvEnv constants (tag/verySimpleAuv.py:106-127)."""
+               xMinMax=(-1., 1.), yMinMax=(-1., 1.), cyl=False):
+    """AuvEnv constants (tag/verySimpleAuv.py:106-127); cyl=True: AuvEnvCyl (tag/verySimpleAuv_cyl.py:29-111 -
+    way-points, +-2 m bounds, "V0" observation scaling)."""
     p = AuvParams()
+    deg = np.pi / 180.
+    if cyl:
+        xMinMax, yMinMax = (-2., 2.), (-2., 2.)
+        wps, thr = cylinder_waypoints()
+        p.n_waypoints = len(wps)
+        p.wp_threshold = thr
+        _fill(p.waypoints, np.concatenate([wps.ravel(), np.zeros(3 * MAX_WAYPOINTS - wps.size)]))
+        _fill(p.obs_scale, [1 / 0.2, 1 / 0.2, 1 / (45. * deg), 1 / (2. * deg), 1 / 0.025, 1 / 0.025, 1 / 0.2, 1 / 0.2,
+                            1 / (30. * deg)])
+    else:
+        p.n_waypoints = 0
+        _fill(p.obs_scale, [1., 1., 1 / (45. * deg), 1., 1., 1., 1., 1., 1.])
     p.m, p.izz = 11.4, 0.16
     p.xuu, p.yvv, p.nrr = -18.18 * 2.21, -21.66 * 4.87, -1.55
     p.xu, p.yv, p.nr = -4.03 * 2.21, -6.22 * 4.87, -0.07

@@ -54,7 +54,7 @@ class _LeanInfos:
 class MarineVecEnv:
     """N BlueROV2 / AUV environments on one GPU.
 
-    model: "rov6" | "rov3" | "auv".  Remaining keyword arguments mirror the reference constructors
+    model: "rov6" | "rov3" | "auv" | "auv_cyl".  Remaining keyword arguments mirror the reference constructors
     (`dt`, `maxSteps` - 6DoF.py:446 / 3DoF.py:376; `noiseMagCoeffs`, `noiseMagActuation`, `currentVelScale`,
     `currentTurbScale`, `stopOnBoundsExceeded` - verySimpleAuv.py:77-78) plus the integrator settings that are
     this build's (`n_substeps`, `control_mode`).
@@ -66,6 +66,10 @@ class MarineVecEnv:
                  fixed_setpoint=False, flow=None, currentVelScale=1.0, currentTurbScale=2.0, noiseMagCoeffs=0.0,
                  noiseMagActuation=0.0, stopOnBoundsExceeded=True, device=0, env_offset=0, infos="dict",
                  vehicle_params=None, precision="f32", integrator="rk4"):
+        cyl = model == "auv_cyl"          # AuvEnvCyl: AuvEnv with way-points (tag/verySimpleAuv_cyl.py)
+        if cyl:
+            model = "auv"
+            maxSteps = 1200 if maxSteps == 250 else maxSteps
         self.model = P.MODEL_NAMES[model] if isinstance(model, str) else int(model)
         self.model_name = {v: k for k, v in P.MODEL_NAMES.items()}[self.model]
         self.num_envs = int(num_envs)
@@ -79,7 +83,7 @@ class MarineVecEnv:
             raise ValueError("AuvEnv needs a turbulence field (flow=ReconstructedFlow(...)): verySimpleAuv.py:102-104")
         kw = {}
         if self.model == P.MODEL_AUV:
-            kw["auv"] = P.auv_params(noiseMagCoeffs, noiseMagActuation, stopOnBoundsExceeded)
+            kw["auv"] = P.auv_params(noiseMagCoeffs, noiseMagActuation, stopOnBoundsExceeded, cyl=cyl)
         elif vehicle_params is not None:
             kw["rov6" if self.model == P.MODEL_ROV6 else "rov3"] = vehicle_params
         self.cfg = P.make_config(self.model, self.num_envs, dt=dt, n_substeps=n_substeps, max_steps=maxSteps,

@@ -634,23 +634,27 @@ int FN(orc_rov_step)(int dof, const mvrl_rov6_params* p6, const mvrl_rov3_params
  * AuvEnv (tag/verySimpleAuv.py).  Per-env fields:
  *   pose[6] = x, y, heading, vx, vy, r (velocities are GLOBAL-frame, :321-326)
  *   tgt[1]  = headingTarget ; err_o[3] = herr_o, perr_o[2] ; mult[11] ; toffset ; hist[10][3] newest first ; istep */
-void FN(orc_auv_obs)(const real pose[6], real heading_target, real* err_o, int has_err_o, real obs[11]) {
-    /* dataToState "V3" (verySimpleAuv.py:147-214); positionTarget = 0 (:241) */
-    real perr[2] = {0 - pose[0], 0 - pose[1]};
-    real herr = FN(orc_angle_error)(heading_target, pose[2]);
+void FN(orc_auv_obs)(const mvrl_auv_params* P, const real pose[6], const real target[3], real* err_o, int has_err_o,
+                     real obs[11]) {
+    /* dataToState: "V3" of AuvEnv (verySimpleAuv.py:201-212, positionTarget = 0 :241) or "V0" of AuvEnvCyl
+     * (verySimpleAuv_cyl.py:100-111) - the two differ only in the divisors, carried by P->obs_scale as reciprocals */
+    real perr[2] = {target[0] - pose[0], target[1] - pose[1]};
+    real herr = FN(orc_angle_error)(target[2], pose[2]);
     if (!has_err_o) { err_o[0] = herr; err_o[1] = perr[0]; err_o[2] = perr[1]; }
-    obs[0] = clip1(perr[0]);
-    obs[1] = clip1(perr[1]);
-    obs[2] = clip1(herr / (real)(45. / 180. * 3.14159265358979323846));
-    obs[3] = clip1(herr - err_o[0]);
-    obs[4] = clip1(perr[0] - err_o[1]);
-    obs[5] = clip1(perr[1] - err_o[2]);
-    obs[6] = clip1(pose[3]); obs[7] = clip1(pose[4]); obs[8] = clip1(pose[5]);
+    const double* sc = P->obs_scale;
+    obs[0] = clip1(perr[0] * (real)sc[0]);
+    obs[1] = clip1(perr[1] * (real)sc[1]);
+    obs[2] = clip1(herr * (real)sc[2]);
+    obs[3] = clip1((herr - err_o[0]) * (real)sc[3]);
+    obs[4] = clip1((perr[0] - err_o[1]) * (real)sc[4]);
+    obs[5] = clip1((perr[1] - err_o[2]) * (real)sc[5]);
+    obs[6] = clip1(pose[3] * (real)sc[6]); obs[7] = clip1(pose[4] * (real)sc[7]); obs[8] = clip1(pose[5] * (real)sc[8]);
     obs[9] = 0; obs[10] = 0;
 }
 
 void FN(orc_auv_step)(const mvrl_auv_params* P, int64_t n, double dt, int max_steps, const real* actions, real* pose,
-                      const real* tgt, real* err_o, const real* mult, const real* toffset, real* hist, int32_t* istep,
+                      real* tgt /* [n][3]: positionTarget, headingTarget */, int32_t* iwp, real* err_o, const real* mult,
+                      const real* toffset, real* hist, int32_t* istep,
                       const real* flow_table, int f_nt, int f_ny, int f_nx, double f_dt, double f_dx, double f_dy,
                       real* obs, real* reward, uint8_t* done, real* aux /* [n][11]: Fhydro3, velCurrent2, rmsAc, terms5 */) {
     const real PI = (real)3.14159265358979323846;
@@ -691,12 +695,17 @@ void FN(orc_auv_step)(const mvrl_auv_params* P, int64_t n, double dt, int max_st
         real nvx = ps[3] + acc0 * h, nvy = ps[4] + acc1 * h, nr = ps[5] + acc2 * h;
         real npose[6] = {nx, ny, nh_, nvx, nvy, nr};
         real* eo = err_o + e * 3;
-        FN(orc_auv_obs)(npose, tgt[e], eo, 1, obs + e * 11); /* :329 (herr_o/perr_o from the previous step) */
+        real* tg = tgt + e * 3;
+        FN(orc_auv_obs)(P, npose, tg, eo, 1, obs + e * 11); /* :329 (herr_o/perr_o from the previous step) */
         real bonus = 0;
         if (nx < (real)P->x_min || nx > (real)P->x_max) { if (P->stop_on_bounds) dn = 1; bonus += -100; } /* :335-342 */
         if (ny < (real)P->y_min || ny > (real)P->y_max) { if (P->stop_on_bounds) dn = 1; bonus += -100; }
-        real perr0 = 0 - nx, perr1 = 0 - ny;
-        real herr = FN(orc_angle_error)(tgt[e], nh_);
+        real perr0 = tg[0] - nx, perr1 = tg[1] - ny;
+        real herr = FN(orc_angle_error)(tg[2], nh_);
+        if (P->n_waypoints > 0 && r_sqrt(perr0 * perr0 + perr1 * perr1) < (real)P->wp_threshold) { /* _cyl.py:249-253 */
+            iwp[e] = iwp[e] + 1 < P->n_waypoints ? iwp[e] + 1 : P->n_waypoints - 1;
+            tg[0] = (real)P->waypoints[3 * iwp[e]]; tg[1] = (real)P->waypoints[3 * iwp[e] + 1]; tg[2] = (real)P->waypoints[3 * iwp[e] + 2];
+        }
         eo[0] = herr; eo[1] = perr0; eo[2] = perr1; /* :349-350 */
         real rms = 0; /* :353-355 */
         for (int k = 0; k < 3; k++) {

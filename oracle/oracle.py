@@ -278,7 +278,8 @@ class OracleAuvEnv:
         self.n, self.dt, self.max_steps = n, dt, max_steps
         d = self.o.dtype
         self.pose = np.zeros((n, 6), d)
-        self.tgt = np.zeros(n, d)
+        self.tgt = np.zeros((n, 3), d)          # positionTarget (2), headingTarget
+        self.iwp = np.zeros(n, np.int32)        # AuvEnvCyl way-point index
         self.err_o = np.zeros((n, 3), d)
         self.mult = np.ones((n, 11), d)
         self.toffset = np.zeros(n, d)
@@ -289,20 +290,28 @@ class OracleAuvEnv:
         self.aux = np.zeros((n, 11), d)
 
     def reset(self, init):
-        """init [n,16] = x y heading headingTarget tOffset mult(11)   (verySimpleAuv.py:216-262)."""
+        """init [n,16] = x y heading headingTarget|iWp tOffset mult(11)   (verySimpleAuv.py:216-262, _cyl.py:113-163)."""
         init = np.asarray(init, dtype=np.float64).reshape(self.n, 16)
         self.pose[:] = 0
         self.pose[:, :3] = init[:, :3]
-        self.tgt[:] = init[:, 3]
+        nwp = int(self.o.auv.n_waypoints)
+        if nwp > 0:
+            self.iwp[:] = init[:, 3].astype(np.int32)
+            wps = np.array(self.o.auv.waypoints)[:3 * nwp].reshape(nwp, 3)
+            self.tgt[:] = wps[self.iwp]
+        else:
+            self.tgt[:] = 0
+            self.tgt[:, 2] = init[:, 3]
         self.toffset[:] = init[:, 4]
         self.mult[:] = init[:, 5:16]
         self.hist[:] = 0
         self.istep[:] = 0
         obs = np.zeros((self.n, 11), self.o.dtype)
         f = self.o._f("orc_auv_obs")
-        f.argtypes = [C.c_void_p, self.o.creal, C.c_void_p, C.c_int, C.c_void_p]
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         for i in range(self.n):
-            f(self.pose[i].ctypes.data, self.o.creal(self.tgt[i]), self.err_o[i].ctypes.data, 0, obs[i].ctypes.data)
+            f(C.addressof(self.o.auv), self.pose[i].ctypes.data, self.tgt[i].ctypes.data, self.err_o[i].ctypes.data, 0,
+              obs[i].ctypes.data)
         return obs
 
     def step(self, actions):
@@ -312,11 +321,12 @@ class OracleAuvEnv:
         rew = np.zeros(self.n, o.dtype)
         done = np.zeros(self.n, np.uint8)
         f = o._f("orc_auv_step")
-        f.argtypes = ([C.c_void_p, C.c_int64, C.c_double, C.c_int] + [C.c_void_p] * 8
+        f.argtypes = ([C.c_void_p, C.c_int64, C.c_double, C.c_int] + [C.c_void_p] * 9
                       + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double] + [C.c_void_p] * 4)
         fl = self.flow
         f(C.addressof(o.auv), self.n, float(self.dt), int(self.max_steps), a.ctypes.data, self.pose.ctypes.data,
-          self.tgt.ctypes.data, self.err_o.ctypes.data, self.mult.ctypes.data, self.toffset.ctypes.data,
+          self.tgt.ctypes.data, self.iwp.ctypes.data, self.err_o.ctypes.data, self.mult.ctypes.data,
+          self.toffset.ctypes.data,
           self.hist.ctypes.data, self.istep.ctypes.data,
           None if fl is None else self._flow_table.ctypes.data,
           0 if fl is None else fl.table.shape[0], 0 if fl is None else fl.table.shape[1],

@@ -7,7 +7,7 @@ import pytest
 
 from .conftest import GOLDEN, golden, max_scaled_err
 from marinevehiclereinforcementlearning_amd import params as P
-from marinevehiclereinforcementlearning_amd.envs import AuvEnv, BlueROV2Heavy3DoFEnv, BlueROV2Heavy6DoFEnv
+from marinevehiclereinforcementlearning_amd.envs import AuvEnv, AuvEnvCyl, BlueROV2Heavy3DoFEnv, BlueROV2Heavy6DoFEnv
 from marinevehiclereinforcementlearning_amd.flow import ReconstructedFlow
 from marinevehiclereinforcementlearning_amd.synthetic import synthetic_spod
 from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
@@ -178,3 +178,32 @@ def test_gym_facade_rk45_reproduces_reference_env_step():
         o, r, d, infos = vec.step(np.zeros((8, 3)))
     assert d.all() and infos[0]["TimeLimit.truncated"]
     env.close(); vec.close()
+
+
+@pytest.mark.parametrize("e", [0, 1, 3])
+def test_auvenvcyl_golden_through_facade_and_abi(e):
+    """AuvEnvCyl (tag/verySimpleAuv_cyl.py) goldens: way-point switching, V0 observation, through the Gym facade."""
+    g = golden("g16_auvenv_cyl.npz")
+    env = AuvEnvCyl(flow=golden_flow(), stopOnBoundsExceeded=bool(g["stop_on_bounds"][e]))
+    assert env._max_episode_steps == 1200 and env.xMinMax == [-2, 2] and env.waypoints.shape == (21, 3)
+    env.iWp = int(g["iwp0"][e])
+    obs = env.reset(fixedInitialValues=[g["init"][e, :2].copy(), g["init"][e, 2], None])
+    for k, v in zip(AuvEnv._MULT, g["mult"][e]):
+        setattr(env, k, float(v))
+    env.flowDataTimeOffset = float(g["t_offset"][e])
+    assert np.max(np.abs(obs - g["obs"][e, 0])) < 2e-5
+    for s in range(int(g["n_steps"][e])):
+        obs, reward, done, _ = env.step(g["actions"][e, s])
+        # the V0 scaling multiplies position errors by up to 40: 1e-6 state differences become 4e-5 in the obs
+        assert np.max(np.abs(obs - g["obs"][e, s + 1])) < 2e-4, s
+        assert max_scaled_err(env.position, g["pose"][e, s + 1, :2]) < 1e-5, s
+        assert env.iWp == g["iwp"][e, s + 1], s
+        assert abs(reward - g["reward"][e, s]) < 5e-5 * max(1, abs(g["reward"][e, s])), s
+        assert done == bool(g["done"][e, s])
+    assert env.iWp > g["iwp0"][e] or e == 3
+    env.close()
+    vec = MarineVecEnv("auv_cyl", 128, seed=1, flow=golden_flow())
+    o = vec.reset()
+    assert o.shape == (128, 11) and vec.variant.startswith("auvcyl")
+    vec.step(np.zeros((128, 3), np.float32))
+    vec.close()
