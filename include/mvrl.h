@@ -247,6 +247,20 @@ int mvrl_flow_reconstruct(int32_t device, const float* modes_re, const float* mo
                           const float* coeffs_im, const float* ltm, int32_t n_space3, int32_t n_modes, int32_t n_t,
                           const float* scale_mul, const float* scale_add, float* out);
 
+/* ---- baseline policies of the reference, batched on the device -------------------------------
+ * MVRL_POLICY_PD  : PDController.predict   tag/verySimpleAuv.py:22-50   (P, D gains on obs[:3], oldObs memory, optional noise)
+ * MVRL_POLICY_LOS : LOSNavigation.predict + lineOfSight   3DoF.py:517-607   (obs = [p0(2), p1(2), psi_e], Rnav = 0.5)
+ * obs [n_envs, obs_dim] f32, actions [n_envs, 3] f32. */
+#define MVRL_POLICY_PD 0
+#define MVRL_POLICY_LOS 1
+typedef struct mvrl_policy mvrl_policy;
+int mvrl_policy_create(int32_t kind, int32_t device, int64_t n_envs, int32_t obs_dim, double dt, const double* P, const double* D,
+                       double noise_sigma, double r_nav, uint64_t seed, mvrl_policy** out);
+void mvrl_policy_destroy(mvrl_policy* p);
+int mvrl_policy_reset(mvrl_policy* p);
+int mvrl_policy_predict(mvrl_policy* p, const float* obs, float* actions);
+int mvrl_policy_predict_dev(mvrl_policy* p, const float* obs_dev, float* actions_dev, void* stream);
+
 /* ---- benchmark helpers -------------------------------------------------------------------------------- */
 /* Fill a DEVICE buffer with uniform(lo,hi) f32 from the counter-based generator (key seed, stream `counter`). */
 int mvrl_fill_uniform_dev(mvrl_handle* h, float* dst_dev, int64_t n, uint64_t seed, uint64_t counter, float lo,

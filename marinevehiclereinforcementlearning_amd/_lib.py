@@ -29,6 +29,7 @@ SYMBOLS = [
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
     "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev",
+    "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
 
@@ -98,6 +99,12 @@ def load(path=None):
     lib.mvrl_set_state_f64.argtypes = [vp, vp, C.c_size_t]
     lib.mvrl_get_aux_f64.argtypes = [vp, vp]
     lib.mvrl_get_nfev.argtypes = [vp, vp]
+    lib.mvrl_policy_create.argtypes = [i32, i32, i64, i32, C.c_double, vp, vp, C.c_double, C.c_double, u64, C.POINTER(vp)]
+    lib.mvrl_policy_destroy.argtypes = [vp]
+    lib.mvrl_policy_destroy.restype = None
+    lib.mvrl_policy_reset.argtypes = [vp]
+    lib.mvrl_policy_predict.argtypes = [vp, vp, vp]
+    lib.mvrl_policy_predict_dev.argtypes = [vp, vp, vp, vp]
     if lib.mvrl_abi_version() != P.ABI_VERSION:
         raise MvrlError("libmvrl.so ABI version does not match the Python package")
     _lib = lib

@@ -24,6 +24,9 @@ hipError_t launch_flow_interp(const float* table, int n_t, int n_y, int n_x, int
 hipError_t launch_flow_reconstruct(const float* modes_re, const float* modes_im, const float* coeffs_re,
                                    const float* coeffs_im, const float* ltm, int n_space3, int n_modes, int n_t,
                                    const float* scale_mul, const float* scale_add, float* out, hipStream_t stream);
+hipError_t launch_pd_policy(const float* obs, int obs_dim, float* old_obs, uint8_t* has_old, float* actions, int64_t n, float dt,
+                            const float* P, const float* D, float noise_sigma, uint64_t seed, uint32_t epoch, hipStream_t stream);
+hipError_t launch_los_policy(const float* obs, int obs_dim, float* actions, int64_t n, float Rnav, hipStream_t stream);
 hipError_t launch_fill_uniform(float* dst, int64_t n, uint64_t seed, uint64_t counter, float lo, float hi,
                                hipStream_t stream);
 
