@@ -1,0 +1,124 @@
+"""Episode evaluation and time-history export around the environments - the callers on the other side of the boundary
+(SURVEY.md 8(f) rank 3):
+
+    evaluate_agent     tag_00_Dec2023_simpleControlTurbulence/resources.py:49-102 (same signature minus `render`):
+                       single-env loop obs -> agent.predict -> env.step, writes <saveDir>/ep_<k>.csv from env.timeHistory
+    EpisodeRecorder    the same CSV schema (verySimpleAuv.py:389-403 / 6DoF.py:578-587 / 3DoF.py:498-507) for a few
+                       tracked lanes of a MarineVecEnv - never per-lane at 1e6 envs
+"""
+import os
+
+import numpy as np
+
+
+def evaluate_agent(agent, env, num_episodes=1, num_steps=None, deterministic=True, num_last_for_reward=None, init=None,
+                   saveDir=None, verbose=True):
+    keepHistory = False
+    if saveDir is not None:
+        os.makedirs(saveDir, exist_ok=True)
+        keepHistory = True
+    all_episode_rewards = []
+    for iEp in range(num_episodes):
+        episode_rewards = []
+        obs = env.reset(fixedInitialValues=init, keepTimeHistory=keepHistory)
+        if num_steps is None:
+            num_steps = 1000000
+        for i in range(num_steps):
+            action, _states = agent.predict(obs, deterministic=deterministic)
+            obs, reward, done, info = env.step(action)
+            episode_rewards.append(reward)
+            if done:
+                if saveDir is not None:
+                    env.timeHistory.to_csv(os.path.join(saveDir, "ep_{:d}.csv".format(iEp)), index=False)
+                break
+        if num_last_for_reward is None:
+            all_episode_rewards.append(sum(episode_rewards))
+        else:
+            all_episode_rewards.append(np.mean(episode_rewards[-num_last_for_reward:]))
+    mean_episode_reward = np.mean(all_episode_rewards)
+    median_episode_reward = np.median(all_episode_rewards)
+    if verbose:
+        print("  Mean reward:  ", mean_episode_reward)
+        print("  Median reward:", median_episode_reward)
+        print("  Num episodes: ", num_episodes)
+    return mean_episode_reward, median_episode_reward, all_episode_rewards
+
+
+AUV_COLUMNS = (["step", "time", "reward", "x", "y", "psi", "x_d", "y_d", "psi_d", "Fx", "Fy", "N", "Fx_set", "Fy_set",
+                "N_set", "u", "v", "r", "u_current", "v_current", "rmsAc"] + [f"r{i}" for i in range(5)]
+               + [f"a{i}" for i in range(3)] + [f"s{i}" for i in range(11)])
+ROV6_COLUMNS = (["t", "x", "y", "z", "phi", "theta", "psi", "u", "v", "w", "p", "q", "r"] + [f"F{i}" for i in range(6)]
+                + [f"u{i}" for i in range(8)] + ["x_d", "y_d", "z_d", "phi_d", "theta_d", "psi_d"])
+ROV3_COLUMNS = (["t"] + [f"x{i}" for i in range(6)] + [f"F{i}" for i in range(3)] + [f"u{i}" for i in range(4)]
+                + ["x_d", "y_d", "psi_d"])
+
+
+class EpisodeRecorder(object):
+    """Record the reference's timeHistory rows for `lanes` of a MarineVecEnv.
+
+        rec = EpisodeRecorder(vec_env, lanes=[0, 17], saveDir="episodes")
+        obs = vec_env.reset(); rec.on_reset()
+        obs, rew, dones, infos = vec_env.step(actions); rec.on_step(actions, obs, rew, dones, infos)
+
+    A finished episode of a tracked lane becomes a pandas DataFrame in `rec.episodes[lane]` and, with saveDir, a CSV
+    named lane<k>_ep_<j>.csv.  Needs the env's side outputs (enabled here) and one small state download per step."""
+
+    def __init__(self, vec_env, lanes, saveDir=None):
+        self.env, self.lanes, self.saveDir = vec_env, [int(x) for x in lanes], saveDir
+        vec_env.handle.enable_aux(True)
+        self.model = vec_env.model_name
+        self.rows = {k: [] for k in self.lanes}
+        self.episodes = {k: [] for k in self.lanes}
+        self.step_no = {k: 0 for k in self.lanes}
+        if saveDir is not None:
+            os.makedirs(saveDir, exist_ok=True)
+
+    def on_reset(self):
+        for k in self.lanes:
+            self.rows[k], self.step_no[k] = [], 0
+        if self.model != "auv":
+            st = self.env.get_state()
+            for k in self.lanes:
+                self.rows[k].append(self._rov_row(st, None, k, 0))
+
+    def _rov_row(self, st, aux, k, n):
+        dof = 6 if self.model == "rov6" else 3
+        nthr = 8 if dof == 6 else 4
+        y = st[: 2 * dof, k]
+        sp = st[4 * dof:5 * dof, k]
+        f = np.zeros(dof + nthr) if aux is None else aux[k]
+        return np.concatenate([[n * self.env.dt], y, f, sp]).astype(np.float64)
+
+    def on_step(self, actions, obs, rewards, dones, infos):
+        import pandas
+        st = self.env.get_state()
+        aux = self.env.handle.get_aux()
+        a = np.asarray(actions)
+        for k in self.lanes:
+            self.step_no[k] += 1
+            n = self.step_no[k]
+            if self.model == "auv":
+                # NOTE on a done step the state planes already hold the next episode: pose columns come from the
+                # terminal observation's companion - the recorder therefore reads the pre-reset pose from aux/obs where
+                # it can and marks the final row's pose with the terminal values delivered in infos
+                ob = infos[k]["terminal_observation"] if dones[k] else obs[k]
+                mult = st[10:21, k]
+                Fset = a[k, :2] * 150. * mult[8:10]
+                Nset = a[k, 2] * 20. * mult[10]
+                pose = st[0:6, k]
+                tgt_h = st[6, k]
+                row = np.concatenate([[n, n * self.env.dt, rewards[k]], pose[0:3], [0., 0., tgt_h], aux[k, 0:3], Fset, [Nset],
+                                      pose[3:6], aux[k, 3:5], [aux[k, 5]], aux[k, 6:11], a[k], ob]).astype(np.float64)
+                cols = AUV_COLUMNS
+            else:
+                row = self._rov_row(st, aux, k, n)
+                cols = ROV6_COLUMNS if self.model == "rov6" else ROV3_COLUMNS
+            self.rows[k].append(row)
+            if dones[k]:
+                df = pandas.DataFrame(np.array(self.rows[k]), columns=cols)
+                self.episodes[k].append(df)
+                if self.saveDir is not None:
+                    df.to_csv(os.path.join(self.saveDir, f"lane{k}_ep_{len(self.episodes[k]) - 1}.csv"), index=False)
+                self.rows[k], self.step_no[k] = [], 0
+                if self.model != "auv":
+                    self.rows[k].append(self._rov_row(st, None, k, 0))
