@@ -261,6 +261,16 @@ int mvrl_policy_reset(mvrl_policy* p);
 int mvrl_policy_predict(mvrl_policy* p, const float* obs, float* actions);
 int mvrl_policy_predict_dev(mvrl_policy* p, const float* obs_dev, float* actions_dev, void* stream);
 
+/* ---- learner-side consumer: CustomReplayBuffer.add with symmetry augmentation ----------------
+ * tag/main_02_sbl_contrib_customBuffer.py:76-160.  All pointers are DEVICE pointers.  obs/next_obs [n_envs, 11],
+ * actions [n_envs, 3], reward [n_envs] f32, done [n_envs] u8 as produced by mvrl_step_dev (bit 1 = time limit ->
+ * the buffer's `timeouts`).  The ring buffers are [buffer_size, n_envs, dim].  Writes n_transforms (5, or 1 once the
+ * buffer has rolled over more than twice, :143) consecutive slots starting at `pos`; the caller advances pos. */
+int mvrl_replay_add_sym_dev(int32_t device, const float* obs, const float* next_obs, const float* actions, const float* reward,
+                            const uint8_t* done, int64_t n_envs, float* buf_obs, float* buf_next_obs, float* buf_actions,
+                            float* buf_reward, uint8_t* buf_done, uint8_t* buf_timeout, int64_t buffer_size, int64_t pos,
+                            int32_t n_transforms, void* stream);
+
 /* ---- benchmark helpers -------------------------------------------------------------------------------- */
 /* Fill a DEVICE buffer with uniform(lo,hi) f32 from the counter-based generator (key seed, stream `counter`). */
 int mvrl_fill_uniform_dev(mvrl_handle* h, float* dst_dev, int64_t n, uint64_t seed, uint64_t counter, float lo,

@@ -29,7 +29,7 @@ SYMBOLS = [
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
     "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev",
-    "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
+    "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
 
@@ -99,6 +99,7 @@ def load(path=None):
     lib.mvrl_set_state_f64.argtypes = [vp, vp, C.c_size_t]
     lib.mvrl_get_aux_f64.argtypes = [vp, vp]
     lib.mvrl_get_nfev.argtypes = [vp, vp]
+    lib.mvrl_replay_add_sym_dev.argtypes = [i32] + [vp] * 5 + [i64] + [vp] * 6 + [i64, i64, i32, vp]
     lib.mvrl_policy_create.argtypes = [i32, i32, i64, i32, C.c_double, vp, vp, C.c_double, C.c_double, u64, C.POINTER(vp)]
     lib.mvrl_policy_destroy.argtypes = [vp]
     lib.mvrl_policy_destroy.restype = None

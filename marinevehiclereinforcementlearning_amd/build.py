@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvrl.so")
-SOURCES = ["mvrl_abi.hip", "mvrl_rov6.hip", "mvrl_rov3.hip", "mvrl_auv.hip", "mvrl_flow.hip", "mvrl_policy.hip",
+SOURCES = ["mvrl_abi.hip", "mvrl_rov6.hip", "mvrl_rov3.hip", "mvrl_auv.hip", "mvrl_flow.hip", "mvrl_policy.hip", "mvrl_replay.hip",
            # fp64 twins, generated from the fp32 sources by tools/gen_f64.py at build time
            "gen/mvrl_rov6_f64.hip", "gen/mvrl_rov3_f64.hip", "gen/mvrl_auv_f64.hip"]
 HEADERS = ["mvrl_device.hpp", "mvrl_kernels.hpp", "mvrl_baked.inc", "mvrl_rk45.hpp", "gen/mvrl_device_f64.hpp",

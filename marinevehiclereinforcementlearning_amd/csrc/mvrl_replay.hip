@@ -1,0 +1,56 @@
+// mvrl_replay.hip - the learner-side consumer of the environment's outputs: CustomReplayBuffer.add with its mirror/flip
+// symmetry augmentation (tag_00_Dec2023_simpleControlTurbulence/main_02_sbl_contrib_customBuffer.py:76-160) as one
+// fused device kernel.  Each env row (obs[11], next_obs[11], action[3], reward, done, timeout) is read once and written
+// to up to five consecutive ring slots, each under its own +-1 mask (:109-126).  Pure streaming: 110 B in, 550 B out per env.
+#include "mvrl_kernels.hpp"
+
+namespace mvrl {
+
+__constant__ float kSymObs[5][11] = {
+    {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1},            // "standard"                         :111
+    {-1, -1, 1, 1, -1, -1, -1, -1, 1, 1, 1},      // mirror everything around the origin :113
+    {-1, 1, 1, 1, -1, 1, -1, 1, 1, 1, 1},         // mirror around the y axis            :115
+    {1, -1, 1, 1, 1, -1, 1, -1, 1, 1, 1},         // mirror around the x axis            :116
+    {1, 1, -1, 1, 1, 1, 1, 1, -1, 1, 1}};         // flip the heading                    :118
+__constant__ float kSymAct[5][3] = {{1, 1, 1}, {-1, -1, 1}, {-1, 1, 1}, {1, -1, 1}, {1, 1, -1}};  // :120-126
+
+__global__ __launch_bounds__(MVRL_BLOCK) void replay_add_sym_kernel(const float* __restrict__ obs, const float* __restrict__ next_obs,
+                                                                    const float* __restrict__ act, const float* __restrict__ rew,
+                                                                    const uint8_t* __restrict__ done, const uint8_t* __restrict__ timeout,
+                                                                    int64_t n_envs, float* __restrict__ b_obs, float* __restrict__ b_next,
+                                                                    float* __restrict__ b_act, float* __restrict__ b_rew,
+                                                                    uint8_t* __restrict__ b_done, uint8_t* __restrict__ b_timeout,
+                                                                    int64_t buffer_size, int64_t pos, int n_tr) {
+    const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= n_envs) return;
+    float o[11], no[11], a[3];
+#pragma unroll
+    for (int k = 0; k < 11; k++) { o[k] = obs[i * 11 + k]; no[k] = next_obs[i * 11 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) a[k] = act[i * 3 + k];
+    const float r = rew[i];
+    const uint8_t d = done[i] ? 1 : 0, to = (timeout[i] & 2) ? 1 : 0;   // done bytes carry the time-limit bit (include/mvrl.h)
+    for (int t = 0; t < n_tr; t++) {
+        int64_t slot = pos + t;
+        if (slot >= buffer_size) slot -= buffer_size;                    // the ring wraps inside one add (:156-159)
+        const int64_t row = slot * n_envs + i;
+#pragma unroll
+        for (int k = 0; k < 11; k++) { b_obs[row * 11 + k] = o[k] * kSymObs[t][k]; b_next[row * 11 + k] = no[k] * kSymObs[t][k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) b_act[row * 3 + k] = a[k] * kSymAct[t][k];
+        b_rew[row] = r;
+        b_done[row] = d;
+        b_timeout[row] = to;
+    }
+}
+
+hipError_t launch_replay_add_sym(const float* obs, const float* next_obs, const float* act, const float* rew, const uint8_t* done,
+                                 const uint8_t* timeout, int64_t n_envs, float* b_obs, float* b_next, float* b_act, float* b_rew,
+                                 uint8_t* b_done, uint8_t* b_timeout, int64_t buffer_size, int64_t pos, int n_tr, hipStream_t stream) {
+    dim3 grid((unsigned)((n_envs + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    hipLaunchKernelGGL(replay_add_sym_kernel, grid, block, 0, stream, obs, next_obs, act, rew, done, timeout, n_envs, b_obs, b_next,
+                       b_act, b_rew, b_done, b_timeout, buffer_size, pos, n_tr);
+    return hipGetLastError();
+}
+
+}  // namespace mvrl

@@ -294,3 +294,36 @@ def test_episode_recorder_on_vecenv(tmp_path):
     assert list(df.columns) == ROV6_COLUMNS and len(df) == 7 and abs(df["t"].iloc[-1] - 1.2) < 1e-6
     assert os.path.exists(os.path.join(str(tmp_path), "lane63_ep_1.csv"))
     env.close()
+
+
+def test_symmetry_replay_buffer_matches_restatement():
+    """CustomReplayBuffer.add (main_02...py:76-160) - parity UNPINNED by execution (SB3 is not installable here); the
+    fused kernel is checked bit for bit against the transcription in oracle/replay_ref.py, through ring wrap-around and the
+    nRollovers > 2 cut-off, fed by a real AuvEnv batch on the device."""
+    import torch
+    from oracle.replay_ref import RefBuffer
+    from marinevehiclereinforcementlearning_amd.replay import SymmetryReplayBuffer
+    n, size = 96, 23                       # 23 is not a multiple of 5: an add straddles the end of the ring
+    env = MarineVecEnv("auv", n, seed=8, flow=golden_flow(), maxSteps=7)
+    buf, ref = SymmetryReplayBuffer(size, n), RefBuffer(size, n)
+    obs = env.reset_tensors().clone()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for s in range(40):
+        act = (torch.rand((n, 3), device="cuda", generator=g) * 2 - 1).contiguous()
+        nobs, rew, done = env.step_tensors(act)
+        buf.add(obs, nobs, act, rew, done)
+        d = done.cpu().numpy()
+        ref.add(obs.cpu().numpy(), nobs.cpu().numpy(), act.cpu().numpy(), rew.cpu().numpy(), (d != 0), (d & 2) != 0)
+        assert (buf.pos, buf.full, buf.nRollovers) == (ref.pos, ref.full, ref.nRollovers), s
+        obs = nobs.clone()
+    torch.cuda.synchronize()
+    assert ref.nRollovers > 3             # both regimes (5 slots per add, then 1) were exercised
+    assert np.array_equal(buf.observations.cpu().numpy(), ref.observations)
+    assert np.array_equal(buf.next_observations.cpu().numpy(), ref.next_observations)
+    assert np.array_equal(buf.actions.cpu().numpy(), ref.actions)
+    assert np.array_equal(buf.rewards.cpu().numpy(), ref.rewards)
+    assert np.array_equal(buf.dones.cpu().numpy().astype(np.float32), ref.dones)
+    assert np.array_equal(buf.timeouts.cpu().numpy().astype(np.float32), ref.timeouts)
+    o, a, no, d, r = buf.sample(256)
+    assert o.shape == (256, 11) and a.shape == (256, 3) and d.shape == (256,)
+    env.close()
