@@ -31,7 +31,16 @@ class SymmetryReplayBuffer(object):
     def add(self, obs, next_obs, action, reward, done):
         """obs/next_obs [n_envs, 11], action [n_envs, 3], reward [n_envs] float32 tensors, done [n_envs] uint8 tensor (the
         done bytes of step_tensors: bit 1 marks a time-limit truncation and lands in `timeouts`)."""
-        n_tr = 1 if self.nRollovers > 2 else self.N_TRANSFORMS          # main_02...py:143
+        # The reference tests `nRollovers > 2` before EACH transform (main_02...py:143), so a roll-over in the middle of an
+        # add stops the synthetic copies right there: the slots written are always a prefix of the five transforms.
+        n_tr, pos, roll = 0, self.pos, self.nRollovers
+        for i in range(self.N_TRANSFORMS):
+            if roll > 2 and i != 0:
+                continue
+            n_tr += 1
+            pos += 1
+            if pos == self.buffer_size:
+                pos, roll = 0, roll + 1
         for t in (obs, next_obs, action, reward, done):
             assert t.is_cuda and t.is_contiguous()
         _lib.check(self.lib.mvrl_replay_add_sym_dev(
