@@ -33,6 +33,10 @@ WORKLOADS = {
     "c3": dict(model="rov6", n=262144, flow=False, bytes=297, name="6-DoF, 262 144 envs (BASELINE configs[2])"),
     "c2": dict(model="rov3", n=65536, flow=False, bytes=165, name="3-DoF, 65 536 envs (BASELINE configs[1])"),
     "auv": dict(model="auv", n=1048576, flow=True, bytes=389, name="AuvEnv + turbulence, 1 048 576 envs"),
+    "auvcyl": dict(model="auv_cyl", n=1048576, flow=True, bytes=397, name="AuvEnvCyl (way-points) + turbulence, 1 048 576 envs"),
+    # the chain either side of the path, device-resident: PD policy -> AuvEnv step -> symmetry replay-buffer add (x5)
+    "loop": dict(model="auv", n=1048576, flow=True, bytes=389 + 2 * (44 + 12) + 110 + 550, loop=True,
+                 name="closed loop: PDController -> AuvEnv -> CustomReplayBuffer.add, 1 048 576 envs"),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 RING = 8
@@ -148,7 +152,22 @@ def main():
         if world > 1:
             dist.barrier()
 
+    loop_objs = None
+    if wl.get("loop"):
+        from marinevehiclereinforcementlearning_amd.policies import PDController
+        from marinevehiclereinforcementlearning_amd.replay import SymmetryReplayBuffer
+        loop_objs = (PDController(0.02, num_envs=n, device=local_rank), SymmetryReplayBuffer(10, n, device=local_rank),
+                     [env.reset_tensors().clone(), None])
+
     def run_plain(steps):
+        if loop_objs is not None:
+            agent, buf, st = loop_objs
+            for k in range(steps):
+                act = agent.predict_tensors(st[0])
+                nobs, rew, done = env.step_tensors(act)
+                buf.add(st[0], nobs, act, rew, done)
+                st[0].copy_(nobs)
+            return
         for k in range(steps):
             env.step_tensors(ring[k % RING])
 
@@ -227,7 +246,7 @@ def main():
             "metric": "env-steps/sec (whole node) + achieved HBM GB/s, 6-DoF batch", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": wl["name"], "envs_per_gpu": n, "global_envs": world * n, "dt": 0.2 if wl["model"] != "auv" else 0.02,
+            "config": {"workload": wl["name"], "envs_per_gpu": n, "global_envs": world * n, "dt": 0.02 if wl["model"].startswith("auv") else 0.2,
                        "n_substeps": args.n_substeps, "control_mode": args.control_mode, "episode_len": 250,
                        "kernel": env.variant, "actions": f"ring of {RING} pre-generated uniform(-1,1) batches in HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -237,7 +256,7 @@ def main():
             "outputs_finite": finite,
         }
         out.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not wl.get("loop") and wl["model"] != "auv_cyl":
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, flow_np, args.seed)
             except Exception as e:  # noqa: BLE001
