@@ -35,7 +35,9 @@ WORKLOADS = {
     "auv": dict(model="auv", n=1048576, flow=True, bytes=389, name="AuvEnv + turbulence, 1 048 576 envs"),
     "auvcyl": dict(model="auv_cyl", n=1048576, flow=True, bytes=397, name="AuvEnvCyl (way-points) + turbulence, 1 048 576 envs"),
     # the chain either side of the path, device-resident: PD policy -> AuvEnv step -> symmetry replay-buffer add (x5)
-    "loop": dict(model="auv", n=1048576, flow=True, bytes=389 + 2 * (44 + 12) + 110 + 550, loop=True,
+    # bytes: what must touch HBM if every inter-kernel tensor (obs, action, reward, done) stayed on chip: AuvEnv state
+    # read + write + flow gathers (328) + the five ring-slot writes (550)
+    "loop": dict(model="auv", n=1048576, flow=True, bytes=328 + 550, loop=True,
                  name="closed loop: PDController -> AuvEnv -> CustomReplayBuffer.add, 1 048 576 envs"),
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
