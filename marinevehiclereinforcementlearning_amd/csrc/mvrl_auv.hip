@@ -6,6 +6,9 @@
 // ring the reward's smoothness term needs), so the layout work - SoA planes, one coalesced read + one
 // coalesced write per word - is what matters here.
 #include "mvrl_kernels.hpp"
+#ifndef MVRL_AUV_LDS_OBS
+#define MVRL_AUV_LDS_OBS 1
+#endif
 
 namespace mvrl {
 
@@ -181,8 +184,31 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
 #pragma unroll
         for (int k = 0; k < 3; k++) ST(AV_HIST + 3 * slot + k) = (k == 0) ? a0 : ((k == 1) ? a1 : a2);
     }
+#if MVRL_AUV_LDS_OBS
+    {   // Row-major [n, 11] observations: written lane-by-lane each store instruction scatters 4-byte pieces over 44-byte
+        // strides (partial cache lines).  Transposing the wave's 64 x 11 tile through LDS turns them into 11 stores of
+        // 256 contiguous bytes.  Wave-private region, stride 11 (odd) -> conflict-free; only the tail wave of the grid
+        // can be partial, and it takes the scattered path.
+        __shared__ float tile[(MVRL_BLOCK / 64) * 64 * 11];
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const uint32_t wave_base = (blockIdx.x * MVRL_BLOCK + wave * 64u);
+        float* t = tile + wave * 704u;
+        if (wave_base + 64u <= (uint32_t)io.n) {
+#pragma unroll
+            for (int q = 0; q < 11; q++) t[lane * 11u + q] = o[q];
+            __builtin_amdgcn_wave_barrier();
+            float* dst = io.obs + (size_t)wave_base * 11;
+#pragma unroll
+            for (int q = 0; q < 11; q++) dst[q * 64u + lane] = t[q * 64u + lane];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 11; q++) io.obs[(size_t)i * 11 + q] = o[q];
+        }
+    }
+#else
 #pragma unroll
     for (int q = 0; q < 11; q++) io.obs[(size_t)i * 11 + q] = o[q];
+#endif
     ST(AV_X) = x; ST(AV_Y) = y; ST(AV_PSI) = psi; ST(AV_VX) = vx; ST(AV_VY) = vy; ST(AV_R) = r;
     ST(AV_HERR_O) = herr_o; ST(AV_PERR_O) = perr_ox; ST(AV_PERR_O + 1) = perr_oy;
     if (cyl || (done && io.auto_reset)) ST(AV_TGT) = tgt;   // the target only changes on way-point switches / new episodes

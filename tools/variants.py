@@ -11,6 +11,7 @@ sys.path.insert(0, REPO)
 OUT = os.path.join(REPO, "variants_build")  # *.so is git-ignored; gpurun_out/ does not travel to the GPU box
 VARIANTS = {
     "base": dict(extra=[], drop=()),
+    "auvscatter": dict(extra=["-DMVRL_AUV_LDS_OBS=0"], drop=()),
     "lds0": dict(extra=["-DMVRL_LDS_STATE=0"], drop=()),
     "w4lds0": dict(extra=["-DMVRL_LDS_STATE=0", "-DMVRL_MIN_WAVES=4"], drop=()),
     "blk256": dict(extra=["-DMVRL_STEP_BLOCK=256"], drop=()),
@@ -46,7 +47,7 @@ def build_all(names):
 def run_all(names):
     for name in names:
         env = dict(os.environ, MVRL_LIB=os.path.join(OUT, f"libmvrl_{name}.so"))
-        for wlk in ("c4", "c3"):
+        for wlk in (os.environ.get("MVRL_VARIANT_WORKLOADS", "c4,c3").split(",")):
             r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", wlk, "--steps", "100", "--warmup",
                                 "10", "--no-cpu-baseline"], env=env, capture_output=True, text=True)
             import json
