@@ -187,8 +187,7 @@ def main():
             b = k & 1
             if k >= 2:
                 main.wait_event(ev_gather[b])          # buffer b is free again once gather k-2 has finished
-            obs, rew, done = env.step_tensors(ring[k % RING])
-            gather[b].pack(obs, rew, done)             # packs into this buffer's send tensor on the main stream
+            env.step_tensors(ring[k % RING], out=gather[b].out_views())   # kernel writes the message in place
             ev_step[b].record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev_step[b])

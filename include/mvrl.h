@@ -12,8 +12,12 @@
  *     available through mvrl_last_error(); no exception crosses the ABI;
  *   - one handle = one device, one internal HIP stream, one host thread at a time;
  *   - host-pointer entry points (`mvrl_step`, `mvrl_reset`, ...) are synchronous on return;
- *     `*_dev` entry points take DEVICE pointers, enqueue on the given stream (NULL = the
- *     handle's own stream) and return after enqueue;
+ *     `*_dev` entry points take DEVICE pointers, enqueue on the caller's hipStream_t, taken
+ *     literally (NULL is HIP's null stream - what torch's default stream is), and return
+ *     after enqueue; an event recorded behind each such enqueue orders any later
+ *     host-pointer call (which runs on the handle's internal stream) after it, so e.g.
+ *     mvrl_get_state after mvrl_step_dev needs no explicit synchronisation; a caller that
+ *     switches between several of its own streams orders them itself;
  *   - actions / observations are row-major [n_envs, dim] float32 at the ABI (what the
  *     reference's Gym API and SB3's VecEnv exchange); internal state is SoA in HBM;
  *   - the library owns all device buffers; it never retains a caller pointer past a call.

@@ -36,11 +36,13 @@ def init_from_env(backend=None):
 
 
 class OutputGather:
-    """Per-step gather of the shards' (obs, reward, done) to `root`.
+    """Per-step gather of the shards' (obs, reward, done) to `root`: ONE message per rank and step.
 
-    Rows are padded to the largest shard so that every rank sends the same shape (a requirement of
-    dist.gather); root returns views trimmed and concatenated in global env order.  `mode="all"` all-gathers
-    instead (every rank ends up with the full batch - for a replicated policy)."""
+    The message is planar - obs[cmax, obs_dim] f32 | reward[cmax] f32 | done[cmax] u8 (padded to 16 B) - so that the
+    step kernel can write its outputs straight into it (`out_views()` handed to `MarineVecEnv.step_tensors(out=...)`):
+    there is no pack kernel and no extra HBM pass between the env step and the wire.  Every rank sends the same
+    number of bytes (a requirement of dist.gather), sized for the largest shard.  `mode="all"` all-gathers instead
+    (every rank ends up with the full batch - for a replicated policy)."""
 
     def __init__(self, n_global, obs_dim, device, root=0, mode="root", group=None):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -49,32 +51,47 @@ class OutputGather:
         self.n_global, self.obs_dim = int(n_global), int(obs_dim)
         self.ranges = [shard_range(n_global, r, self.world) for r in range(self.world)]
         self.cmax = max(c for _, c in self.ranges)
+        self.count = self.ranges[self.rank][1]
         self.device = device
-        self.row = obs_dim + 2  # obs | reward | done (as f32: one message instead of three)
-        self.send = torch.zeros((self.cmax, self.row), dtype=torch.float32, device=device)
+        self.off_rew = self.cmax * self.obs_dim * 4
+        self.off_done = self.off_rew + self.cmax * 4
+        self.msg_bytes = (self.off_done + self.cmax + 15) // 16 * 16
+        self.send = torch.zeros((self.msg_bytes,), dtype=torch.uint8, device=device)
         need_recv = (mode == "all") or (self.rank == root)
-        self.recv = torch.zeros((self.world, self.cmax, self.row), dtype=torch.float32, device=device) if need_recv else None
-        self.even = all(c == self.cmax for _, c in self.ranges)
+        self.recv = torch.zeros((self.world, self.msg_bytes), dtype=torch.uint8, device=device) if need_recv else None
 
     def bytes_per_step(self):
-        return self.world * self.cmax * self.row * 4
+        """Bytes arriving at the root (or at every rank in mode "all") per env step of the global batch."""
+        return self.world * self.msg_bytes
+
+    def _views(self, buf, c):
+        obs = buf[: self.off_rew].view(torch.float32).view(self.cmax, self.obs_dim)[:c]
+        rew = buf[self.off_rew: self.off_done].view(torch.float32)[:c]
+        done = buf[self.off_done: self.off_done + self.cmax][:c]
+        return obs, rew, done
+
+    def out_views(self):
+        """(obs[c, obs_dim] f32, reward[c] f32, done[c] u8): contiguous views INTO the send message for this rank's
+        shard.  A producer that writes them (the step kernel) makes `pack` unnecessary."""
+        return self._views(self.send, self.count)
 
     def pack(self, obs, reward, done):
-        c = obs.shape[0]
-        self.send[:c, : self.obs_dim].copy_(obs)
-        self.send[:c, self.obs_dim].copy_(reward)
-        self.send[:c, self.obs_dim + 1].copy_(done)
+        """Copy path for producers that own their output buffers."""
+        o, r, d = self._views(self.send, obs.shape[0])
+        o.copy_(obs)
+        r.copy_(reward)
+        d.copy_(done)
         return self.send
 
     def exchange(self):
-        if self.world == 1:
+        if not dist.is_initialized():        # plain single process: no process group to talk to
             if self.recv is not None:
                 self.recv[0].copy_(self.send)
             return
         if self.send.is_cuda and dist.get_backend(self.group) == "gloo":
             return self._exchange_via_host()  # rehearsal path: gloo has no device-side gather
         if self.mode == "all":
-            dist.all_gather_into_tensor(self.recv.view(-1, self.row), self.send, group=self.group)
+            dist.all_gather_into_tensor(self.recv.view(-1), self.send, group=self.group)
         else:
             if self.rank == self.root:
                 dist.gather(self.send, gather_list=list(self.recv.unbind(0)), dst=self.root, group=self.group)
@@ -84,8 +101,8 @@ class OutputGather:
     def _exchange_via_host(self):
         send = self.send.cpu()
         if self.mode == "all":
-            out = torch.empty((self.world,) + tuple(send.shape), dtype=send.dtype)
-            dist.all_gather_into_tensor(out.view(-1, self.row), send, group=self.group)
+            out = torch.empty((self.world, self.msg_bytes), dtype=send.dtype)
+            dist.all_gather_into_tensor(out.view(-1), send, group=self.group)
             self.recv.copy_(out)
         elif self.rank == self.root:
             parts = [torch.empty_like(send) for _ in range(self.world)]
@@ -94,16 +111,22 @@ class OutputGather:
         else:
             dist.gather(send, gather_list=None, dst=self.root, group=self.group)
 
-    def unpack(self):
-        """On root (or everywhere in mode "all"): (obs[N, obs_dim], reward[N], done[N] u8) in global env order.
-        obs and reward are VIEWS into the receive buffer: valid until the next exchange."""
+    def unpack_shards(self):
+        """On root (or everywhere in mode "all"): one (obs, reward, done) triple of VIEWS into the receive buffer per
+        rank, in global env order - no copy; valid until the next exchange."""
         if self.recv is None:
             return None
-        if self.even:
-            flat = self.recv.view(-1, self.row)
-        else:
-            flat = torch.cat([self.recv[r, :c] for r, (_, c) in enumerate(self.ranges)], dim=0)
-        return flat[:, : self.obs_dim], flat[:, self.obs_dim], flat[:, self.obs_dim + 1].to(torch.uint8)
+        return [self._views(self.recv[r], c) for r, (_, c) in enumerate(self.ranges)]
+
+    def unpack(self):
+        """On root (or everywhere in mode "all"): (obs[N, obs_dim], reward[N], done[N] u8) in global env order
+        (one concatenation of the shard views)."""
+        shards = self.unpack_shards()
+        if shards is None:
+            return None
+        if len(shards) == 1:
+            return shards[0]
+        return tuple(torch.cat([sh[k] for sh in shards], dim=0) for k in range(3))
 
     def __call__(self, obs, reward, done):
         self.pack(obs, reward, done)
@@ -134,7 +157,11 @@ class ShardedVecEnv:
         return None if out is None else out[0]
 
     def step(self, actions_local):
-        obs, rew, done = self.local.step_tensors(actions_local)
         if self.gather is None:
-            return obs, rew, done
-        return self.gather(obs, rew, done)
+            return self.local.step_tensors(actions_local)
+        if getattr(self.local, "supports_out", False):
+            # zero-copy: the step kernel writes obs / reward / done straight into the gather message
+            self.local.step_tensors(actions_local, out=self.gather.out_views())
+            self.gather.exchange()
+            return self.gather.unpack()
+        return self.gather(*self.local.step_tensors(actions_local))

@@ -196,14 +196,25 @@ class MarineVecEnv:
         self._h.reset_dev(None, None, obs.data_ptr(), torch.cuda.current_stream().cuda_stream)
         return obs
 
-    def step_tensors(self, actions):
+    supports_out = True
+
+    def step_tensors(self, actions, out=None):
         """Device-resident step: `actions` is a contiguous float32 CUDA(HIP) tensor [N, act_dim]; returns
         (obs, reward, done_bits) tensors that are overwritten by the next call.  Enqueued on torch's current stream;
-        nothing crosses PCIe."""
+        nothing crosses PCIe.  `out=(obs, reward, done)` makes the kernel write into caller-owned contiguous tensors
+        instead (e.g. the views of a gather message, `distributed.OutputGather.out_views()`)."""
         import torch
         assert actions.is_cuda and actions.is_contiguous()
-        assert actions.dtype == (torch.float64 if self._h.f64 else torch.float32)
-        obs, rew, done = self._ensure_tensors()
+        rt = torch.float64 if self._h.f64 else torch.float32
+        assert actions.dtype == rt
+        if out is not None:
+            obs, rew, done = out
+            n, od = self.num_envs, self.observation_space.shape[0]
+            assert obs.is_cuda and obs.is_contiguous() and obs.dtype == rt and tuple(obs.shape) == (n, od)
+            assert rew.is_cuda and rew.is_contiguous() and rew.dtype == rt and tuple(rew.shape) == (n,)
+            assert done.is_cuda and done.is_contiguous() and done.dtype == torch.uint8 and tuple(done.shape) == (n,)
+        else:
+            obs, rew, done = self._ensure_tensors()
         self._h.step_dev(actions.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
                          torch.cuda.current_stream().cuda_stream)
         return obs, rew, done

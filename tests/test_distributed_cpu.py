@@ -24,8 +24,9 @@ def free_port():
 class OracleShard:
     """CPU stepper with the step_tensors/reset_tensors interface; per-env inputs are functions of the GLOBAL id."""
 
-    def __init__(self, offset, count, n_global, steps_seed=3):
+    def __init__(self, offset, count, n_global, supports_out=False):
         from oracle import oracle as orc
+        self.supports_out = supports_out
         self.env = orc.OracleRovEnv(6, count, "f64", n_substeps=2, max_steps=10 ** 9)
         rng = np.random.default_rng(5)
         init = np.concatenate([(rng.random((n_global, 6)) - 0.5) * 10, rng.random((n_global, 3)) * 2 * np.pi], axis=1)
@@ -34,16 +35,22 @@ class OracleShard:
     def reset_tensors(self):
         return torch.from_numpy(self.env.reset(self.init)).float()
 
-    def step_tensors(self, actions):
+    def step_tensors(self, actions, out=None):
         o, r, d = self.env.step(actions.numpy().astype(np.float64))
-        return torch.from_numpy(o).float(), torch.from_numpy(r).float(), torch.from_numpy(d)
+        res = torch.from_numpy(o).float(), torch.from_numpy(r).float(), torch.from_numpy(d)
+        if out is None:
+            return res
+        for dst, src in zip(out, res):  # the producer writes the gather message in place (MarineVecEnv out=)
+            assert dst.is_contiguous() and dst.shape == src.shape and dst.dtype == src.dtype
+            dst.copy_(src)
+        return out
 
 
-def worker(rank, world, port, n_global, mode, q):
+def worker(rank, world, port, n_global, mode, q, inplace=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, w, _ = D.init_from_env("gloo")
     assert (r, w) == (rank, world)
-    env = D.ShardedVecEnv(lambda off, cnt, rk: OracleShard(off, cnt, n_global), n_global, 9, torch.device("cpu"), gather=mode)
+    env = D.ShardedVecEnv(lambda off, cnt, rk: OracleShard(off, cnt, n_global, inplace), n_global, 9, torch.device("cpu"), gather=mode)
     acts = torch.from_numpy(np.random.default_rng(9).uniform(-1, 1, size=(4, n_global, 6))).float()
     def keep(x):  # gathered outputs are views into the receive buffer, valid until the next call
         return None if x is None else (x.clone() if torch.is_tensor(x) else tuple(t.clone() for t in x))
@@ -56,11 +63,11 @@ def worker(rank, world, port, n_global, mode, q):
     dist.destroy_process_group()
 
 
-def run_world(n_global, mode, world=2):
+def run_world(n_global, mode, world=2, inplace=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, n_global, mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, n_global, mode, q, inplace)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world if mode == "all" else 1)]
@@ -86,11 +93,13 @@ def test_shard_range_partitions_everything():
         assert max(c for _, c in rs) - min(c for _, c in rs) <= 1
 
 
-@pytest.mark.parametrize("n_global,mode", [(16, "root"), (11, "root"), (11, "all")])
-def test_two_rank_gather_equals_single_process(n_global, mode):
-    """Concatenation of the shards == the unsharded batch, bit for bit (even and ragged shards)."""
+@pytest.mark.parametrize("n_global,mode,inplace", [(16, "root", False), (11, "root", False), (11, "all", False),
+                                                  (11, "root", True), (16, "all", True)])
+def test_two_rank_gather_equals_single_process(n_global, mode, inplace):
+    """Concatenation of the shards == the unsharded batch, bit for bit (even and ragged shards; producer-side copy
+    and the zero-copy path where the stepper writes the gather message in place)."""
     ref0, ref = single_process(n_global)
-    for rank, got0, got in run_world(n_global, mode):
+    for rank, got0, got in run_world(n_global, mode, inplace=inplace):
         assert np.array_equal(got0, ref0)
         for s in range(4):
             assert np.array_equal(got[s][0], ref[s][0])
@@ -103,4 +112,9 @@ def test_gather_single_process_passthrough():
     obs, rew, done = torch.rand(5, 3), torch.rand(5), torch.tensor([0, 1, 0, 3, 0], dtype=torch.uint8)
     o, r, d = g(obs, rew, done)
     assert torch.equal(o, obs) and torch.equal(r, rew) and torch.equal(d, done)
-    assert g.bytes_per_step() == 5 * 5 * 4
+    assert g.bytes_per_step() == (5 * 3 * 4 + 5 * 4 + 5 + 15) // 16 * 16
+    o2, r2, d2 = g.out_views()          # zero-copy producer views alias the message
+    o2.fill_(2.0); r2.fill_(3.0); d2.fill_(1)
+    g.exchange()
+    o, r, d = g.unpack()
+    assert float(o.min()) == 2.0 and float(r.max()) == 3.0 and int(d.sum()) == 5

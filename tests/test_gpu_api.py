@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from .conftest import GOLDEN, golden, max_scaled_err
 from marinevehiclereinforcementlearning_amd import params as P
@@ -82,6 +83,77 @@ def test_vecenv_auv_bounds_termination_and_tensors():
     assert np.array_equal(oa, ob.cpu().numpy()) and np.array_equal(da, db.cpu().numpy() != 0)
     for e in (env, a, b):
         e.close()
+
+
+def test_sharded_zero_copy_gather_message():
+    """Two shards (env_offset = global ids) stepping straight into their gather messages == the unsharded batch, bit for
+    bit: the step kernel's out= path, OutputGather's planar message and the global-id keyed RNG (distributed.py)."""
+    from marinevehiclereinforcementlearning_amd import distributed as D
+    from marinevehiclereinforcementlearning_amd.flow import ReconstructedFlow
+    n, dev = 4096 + 37, torch.device("cuda", 0)
+    flow = ReconstructedFlow.synthetic(n_modes=4, n_time=64, device=0)
+    flow.scale(11., 1., 2., translate=(-1.65, -1.1))
+    full = MarineVecEnv("rov6", n, seed=11, flow=flow, maxSteps=7)
+    act = torch.from_numpy(np.random.default_rng(4).uniform(-1, 1, size=(12, n, 6)).astype(np.float32)).cuda()
+    ranges = [D.shard_range(n, r, 2) for r in range(2)]
+    shards = [MarineVecEnv("rov6", c, seed=11, flow=flow, maxSteps=7, env_offset=o) for o, c in ranges]
+    full.reset_tensors()
+    for sh in shards:
+        sh.reset_tensors()
+    # one single-rank gather object per shard stands in for the two ranks' send buffers
+    msgs = [D.OutputGather(c, 9, dev) for _, c in ranges]
+    for k in range(12):                       # crosses an auto-reset (maxSteps = 7)
+        o, r, d = full.step_tensors(act[k])
+        parts = []
+        for (off, c), sh, g in zip(ranges, shards, msgs):
+            views = g.out_views()
+            got = sh.step_tensors(act[k, off:off + c].contiguous(), out=views)
+            assert got[0].data_ptr() == views[0].data_ptr() == g.send.data_ptr()
+            g.exchange()
+            parts.append(g.unpack())
+        for j, t in enumerate((o, r, d)):
+            assert torch.equal(t, torch.cat([p[j] for p in parts]))
+    with pytest.raises(AssertionError):
+        shards[0].step_tensors(act[0, :ranges[0][1]].contiguous(), out=(o, r, d))   # wrong shapes are refused
+    for e in [full] + shards:
+        e.close()
+
+
+def test_gather_message_through_rccl_single_rank():
+    """The collective calls of OutputGather on the real backend ("nccl" = RCCL), world size 1 (one GPU on this box):
+    uint8 message tensors, gather-to-root and all-gather, issued on a side stream as bench.py --gpus N does."""
+    import socket
+    import torch.distributed as dist
+    from marinevehiclereinforcementlearning_amd import distributed as D
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        env = MarineVecEnv("rov6", 2048, seed=3)
+        env.reset_tensors()
+        act = torch.rand((2048, 6), device="cuda") * 2 - 1
+        ref = [t.clone() for t in env.step_tensors(act)]
+        st = env.get_state()
+        for mode in ("root", "all"):
+            env2 = MarineVecEnv("rov6", 2048, seed=3)
+            env2.reset_tensors()
+            g = D.OutputGather(2048, 9, torch.device("cuda", 0), mode=mode)
+            side = torch.cuda.Stream()
+            env2.step_tensors(act, out=g.out_views())
+            ev = torch.cuda.Event(); ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                g.exchange()
+            torch.cuda.current_stream().wait_stream(side)
+            got = g.unpack()
+            torch.cuda.synchronize()
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b)
+            assert np.array_equal(st, env2.get_state())
+            env2.close()
+        env.close()
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("cls,dof,name", [(BlueROV2Heavy6DoFEnv, 6, "g09_rk4_6dof_fixedsp_nsub4.npz"),
