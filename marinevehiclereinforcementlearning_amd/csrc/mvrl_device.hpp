@@ -148,24 +148,37 @@ struct FlowDev {
 
 // ReconstructedFlow.interp restricted to (u, v) (tag/flowGenerator.py:97-136): cell index clamped, weights NOT
 // clamped (linear extrapolation outside the table), origin ignored - all as the reference.
-__device__ __forceinline__ float2 flow_interp_uv(const FlowDev& f, float time, float x, float y) {
+// Split in two so that a kernel can issue the gathers early and consume them late (the loads are a dependent HBM /
+// Infinity-Cache round trip): flow_gather = index arithmetic + the 8 loads, flow_combine = the interpolation.
+struct FlowTap {
+    float2 c000, c001, c010, c011, c100, c101, c110, c111;
+    float ft, fx, fy;
+};
+__device__ __forceinline__ FlowTap flow_gather(const FlowDev& f, float time, float x, float y) {
+    FlowTap g;
     float tt = time * f.inv_dt, xx = x * f.inv_dx, yy = y * f.inv_dy;
     int kk = min(f.n_t - 2, max(0, (int)floorf(tt)));
     int ii = min(f.n_x - 2, max(0, (int)floorf(xx)));
     int jj = min(f.n_y - 2, max(0, (int)floorf(yy)));
-    float ft = tt - (float)kk, fx = xx - (float)ii, fy = yy - (float)jj;
-    float wt0 = 1.f - ft, wx0 = 1.f - fx, wy0 = 1.f - fy;
+    g.ft = tt - (float)kk; g.fx = xx - (float)ii; g.fy = yy - (float)jj;
     const float2* p0 = f.table + ((size_t)kk * f.n_y + jj) * f.n_x + ii;
     const float2* p1 = p0 + (size_t)f.n_y * f.n_x;
     // 8 corner gathers of 8 B each (entries are only 8-byte aligned, so no 16-byte loads); the x-neighbours are
     // adjacent in memory and share a cache line almost always.
-    float2 c000 = p0[0], c001 = p0[1], c010 = p0[f.n_x], c011 = p0[f.n_x + 1];
-    float2 c100 = p1[0], c101 = p1[1], c110 = p1[f.n_x], c111 = p1[f.n_x + 1];
-    float u0 = wy0 * (c000.x * wx0 + c001.x * fx) + fy * (c010.x * wx0 + c011.x * fx);
-    float v0 = wy0 * (c000.y * wx0 + c001.y * fx) + fy * (c010.y * wx0 + c011.y * fx);
-    float u1 = wy0 * (c100.x * wx0 + c101.x * fx) + fy * (c110.x * wx0 + c111.x * fx);
-    float v1 = wy0 * (c100.y * wx0 + c101.y * fx) + fy * (c110.y * wx0 + c111.y * fx);
+    g.c000 = p0[0]; g.c001 = p0[1]; g.c010 = p0[f.n_x]; g.c011 = p0[f.n_x + 1];
+    g.c100 = p1[0]; g.c101 = p1[1]; g.c110 = p1[f.n_x]; g.c111 = p1[f.n_x + 1];
+    return g;
+}
+__device__ __forceinline__ float2 flow_combine(const FlowTap& g) {
+    const float wt0 = 1.f - g.ft, wx0 = 1.f - g.fx, wy0 = 1.f - g.fy, fx = g.fx, fy = g.fy, ft = g.ft;
+    float u0 = wy0 * (g.c000.x * wx0 + g.c001.x * fx) + fy * (g.c010.x * wx0 + g.c011.x * fx);
+    float v0 = wy0 * (g.c000.y * wx0 + g.c001.y * fx) + fy * (g.c010.y * wx0 + g.c011.y * fx);
+    float u1 = wy0 * (g.c100.x * wx0 + g.c101.x * fx) + fy * (g.c110.x * wx0 + g.c111.x * fx);
+    float v1 = wy0 * (g.c100.y * wx0 + g.c101.y * fx) + fy * (g.c110.y * wx0 + g.c111.y * fx);
     return make_float2(u0 * wt0 + u1 * ft, v0 * wt0 + v1 * ft);
+}
+__device__ __forceinline__ float2 flow_interp_uv(const FlowDev& f, float time, float x, float y) {
+    return flow_combine(flow_gather(f, time, x, y));
 }
 
 // ---- device mirrors of the model constants (fp32) -------------------------------------------------
@@ -236,6 +249,20 @@ __device__ __forceinline__ PT launder(PT p) {
 }  // namespace mvrl
 #include "mvrl_baked.inc"
 namespace mvrl {
+// A wave-uniform run-time scalar used as a VALU operand lives in an SGPR, and on gfx950 a VALU instruction with an SGPR
+// operand issues at HALF rate (tools/valu_operands.hip: 0.55 vs 1.0 wave-instr/ns/SIMD; literals and inline constants
+// are free).  `in_vgpr` pins such a value to a VGPR once, outside the hot loop.
+__device__ __forceinline__ float in_vgpr(float x) {
+#if MVRL_F64
+    return x;
+#else
+#ifndef MVRL_NO_VGPR_SCALARS
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+#endif
+}
+
 // Baked flavour: `p->field` resolves to a static constexpr member, i.e. an instruction literal; nothing to launder.
 __device__ __forceinline__ const Rov6Baked* launder(const Rov6Baked* p) { return p; }
 __device__ __forceinline__ const Rov3Baked* launder(const Rov3Baked* p) { return p; }

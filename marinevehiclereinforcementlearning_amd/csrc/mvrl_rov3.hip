@@ -206,7 +206,8 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     if (FLOW) cur = flow_interp_uv(fl, (float)istep * io.dt + ST(R3_TOFF), y[0], y[1]);
     if (first) { pid.eold[0] = sp[0] - y[0]; pid.eold[1] = sp[1] - y[1]; pid.eold[2] = angle_error(sp[2], y[2]); }
 
-    const float h = io.dt / (float)io.n_sub, hh = 0.5f * h, h6 = h / 6.f, inv_hh = 1.0f / hh;
+    const float h_s = io.dt / (float)io.n_sub;
+    const float h = in_vgpr(h_s), hh = in_vgpr(0.5f * h_s), h6 = in_vgpr(h_s / 6.f), inv_hh = in_vgpr(1.0f / (0.5f * h_s));
     float* const aux_row = io.aux ? io.aux + (size_t)i_in * 7 : nullptr;
     float inc_prev[3] = {0.f, 0.f, 0.f};  // see mvrl_rov6.hip
 #if MVRL_F64

@@ -370,11 +370,26 @@ struct Rhs6 {
 #endif
 
 
+#if defined(MVRL_STAMP) && !MVRL_F64
+#define MVRL_STAMP_ON 1
+// Profiling build only (tools/stamp_probe.py): per-wave s_memtime stamps at the phase boundaries of the step kernel.
+#define MVRL_STAMP_WAVES 32768
+__device__ unsigned long long g_stamp[5 * MVRL_STAMP_WAVES];
+#define STAMP(slot)                                                                                          \
+    do {                                                                                                     \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                \
+        if (threadIdx.x == 0 && blockIdx.x < MVRL_STAMP_WAVES) g_stamp[(slot) * MVRL_STAMP_WAVES + blockIdx.x] = t_; \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 template <class PP, bool SYM, bool ZOH, bool FLOW, int INTEG>
 __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
     const uint32_t i_in = blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
     if (i_in >= (uint32_t)io.n) return;
+    STAMP(0);
     // plane k of env i = state[k * n + i] with a 32-bit element index: the access lowers to the
     // `global_load_dword v, v_off, s[base:base+1]` form (uniform 64-bit base in SGPRs + one 32-bit VGPR offset)
     // instead of a 64-bit VGPR address pair per plane.  The host guarantees words * n < 2^30.
@@ -385,42 +400,56 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
 
     float y[12], sp[6], path[6];
     Pid6 pid;
+    // Issue order matters: vector loads return in order, and the turbulence gathers (a second, dependent HBM round
+    // trip) need only x, y, iStep and the time offset - so those four go first and the gathers can leave while the rest
+    // of the state is still arriving.  A load placed behind the set-point branch below would cost a third round trip
+    // (tools/stamp_probe.py measures the phases).
+    y[0] = ST(R6_Y + 0); y[1] = ST(R6_Y + 1);
+    int istep = unpack_int(ST(R6_ISTEP));
+    float toff = 0.f;
+    if (FLOW) toff = ST(R6_TOFF);
+    asm volatile("" ::: "memory");  // keep the four critical loads first in issue order
 #pragma unroll
-    for (int k = 0; k < 12; k++) y[k] = ST(R6_Y + k);
+    for (int k = 2; k < 12; k++) y[k] = ST(R6_Y + k);
 #pragma unroll
     for (int k = 0; k < 6; k++) { pid.eold[k] = ST(R6_EOLD + k); pid.eint[k] = ST(R6_EINT + k); }
-    int istep = unpack_int(ST(R6_ISTEP));
-
-    if (io.fixed_sp) {  // 6DoF.py:536-541
+    // set-point inputs, branch-free (one basic block up to the RK4 loop lets the gathers leave before anything waits
+    // on the bulk of the state): fixed set-point -> the stored planes (6DoF.py:536-541), else the action row
+    float spin[6];
+    {
+        const float* arow = io.fixed_sp ? nullptr : io.actions + (size_t)i_in * 6;
 #pragma unroll
-        for (int k = 0; k < 6; k++) sp[k] = ST(R6_SP + k);
-    } else {            // 6DoF.py:545-552
-        const float2* ap = reinterpret_cast<const float2*>(io.actions + (size_t)i_in * 6);
-        float2 a01 = ap[0], a23 = ap[1], a45 = ap[2];
-        sp[0] = fmaf(a01.x, p->act_scale[0], y[0]); sp[1] = fmaf(a01.y, p->act_scale[1], y[1]);
-        sp[2] = fmaf(a23.x, p->act_scale[2], y[2]); sp[3] = fmaf(a23.y, p->act_scale[3], y[3]);
-        sp[4] = fmaf(a45.x, p->act_scale[4], y[4]); sp[5] = fmaf(a45.y, p->act_scale[5], y[5]);
+        for (int k = 0; k < 6; k++) spin[k] = io.fixed_sp ? ST(R6_SP + k) : arow[k];
     }
     const bool first = (istep == 0);  // controller.eOld is None until the first call (6DoF.py:62-63)
     istep += 1;                       // 6DoF.py:533
-
-    float2 cur = make_float2(0.f, 0.f);
-    if (FLOW) {  // sampled once per env step at the pre-step position, time AFTER the increment
-        float toff = ST(R6_TOFF);
-        cur = flow_interp_uv(fl, (float)istep * io.dt + toff, y[0], y[1]);
-    }
+    FlowTap tap;
+    if (FLOW)  // sampled once per env step at the pre-step position, time AFTER the increment
+        tap = flow_gather(fl, (float)istep * io.dt + toff, y[0], y[1]);
+#pragma unroll
+    for (int k = 0; k < 6; k++)  // 6DoF.py:545-552
+        sp[k] = io.fixed_sp ? spin[k] : fmaf(spin[k], p->act_scale[k], y[k]);
     if (first) {
         pid.eold[0] = sp[0] - y[0]; pid.eold[1] = sp[1] - y[1]; pid.eold[2] = sp[2] - y[2];
         pid.eold[3] = sp[3] - y[3]; pid.eold[4] = sp[4] - y[4]; pid.eold[5] = angle_error(sp[5], y[5]);
     }
 
-    const float h = io.dt / (float)io.n_sub;
-    const float hh = 0.5f * h, h6 = h / 6.f;
-    const float inv_hh = 1.0f / hh;
+    const float h_s = io.dt / (float)io.n_sub;
+    const float h = in_vgpr(h_s), hh = in_vgpr(0.5f * h_s), h6 = in_vgpr(h_s / 6.f);
+    const float inv_hh = in_vgpr(1.0f / (0.5f * h_s));
+    float2 cur = make_float2(0.f, 0.f);
+    if (FLOW) cur = flow_combine(tap);
     float* const aux_row = io.aux ? io.aux + (size_t)i_in * 14 : nullptr;
     // pose increment between the last PID call of a sub-step and the first of the next; not known across env steps
     // (new set-point, angle wrap): the first call of a step uses the rounded difference (inc_valid = false)
     float inc_prev[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef MVRL_STAMP_ON
+    {   // everything the loop needs has arrived
+        float dep = y[0] + y[11] + pid.eint[5] + pid.eold[5] + sp[5] + cur.x;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(dep));
+        STAMP(1);
+    }
+#endif
 #if MVRL_F64
     if (INTEG == 1) {
         // the reference's own integrator: fresh adaptive RK45 solve over (time - dt, time)
@@ -491,6 +520,10 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
 #pragma unroll
         for (int q = 0; q < 12; q++) y[q] = fmaf(h6, acc[q] + k[q], y[q]);
     }
+#ifdef MVRL_STAMP_ON
+    asm volatile("" : "+v"(y[0]), "+v"(y[11]));
+    STAMP(2);
+#endif
     // 6DoF.py:560
     y[3] = mod_two_pi(y[3]); y[4] = mod_two_pi(y[4]); y[5] = mod_two_pi(y[5]);
     // The epilogue addresses the same SoA planes as the prologue.  Left alone, LLVM keeps all ~40 prologue
@@ -547,7 +580,18 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
         for (int k = 0; k < 6; k++) ST(R6_SP + k) = sp[k];
     }
     ST(R6_ISTEP) = pack_int(istep);
+#ifdef MVRL_STAMP_ON
+    STAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)");
+    STAMP(4);
+#endif
 }
+
+#ifdef MVRL_STAMP_ON
+extern "C" int mvrl_debug_stamps(unsigned long long* dst, size_t n_words) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamp), n_words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // reset (6DoF.py:485-529): mask/init may be null.
 __global__ __launch_bounds__(MVRL_BLOCK) void rov6_reset_kernel(const Rov6Dev* __restrict__ pg, float* state, int64_t n, const uint8_t* mask,

@@ -11,6 +11,10 @@ sys.path.insert(0, REPO)
 OUT = os.path.join(REPO, "variants_build")  # *.so is git-ignored; gpurun_out/ does not travel to the GPU box
 VARIANTS = {
     "base": dict(extra=[], drop=()),
+    "stamp": dict(extra=["-DMVRL_STAMP"], drop=()),
+    "novs": dict(extra=["-DMVRL_NO_VGPR_SCALARS"], drop=()),
+    "ilp": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp"], drop=()),
+    "ilpw3": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-DMVRL_MIN_WAVES=3"], drop=()),
     "auvscatter": dict(extra=["-DMVRL_AUV_LDS_OBS=0"], drop=()),
     "lds0": dict(extra=["-DMVRL_LDS_STATE=0"], drop=()),
     "w4lds0": dict(extra=["-DMVRL_LDS_STATE=0", "-DMVRL_MIN_WAVES=4"], drop=()),
