@@ -52,8 +52,8 @@ def run_all(names):
     for name in names:
         env = dict(os.environ, MVRL_LIB=os.path.join(OUT, f"libmvrl_{name}.so"))
         for wlk in (os.environ.get("MVRL_VARIANT_WORKLOADS", "c4,c3").split(",")):
-            r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", wlk, "--steps", "100", "--warmup",
-                                "10", "--no-cpu-baseline"], env=env, capture_output=True, text=True)
+            r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", wlk, "--steps", "3000", "--warmup",
+                                "500", "--no-cpu-baseline"], env=env, capture_output=True, text=True)
             import json
             try:
                 j = json.loads(r.stdout.strip().splitlines()[-1])
