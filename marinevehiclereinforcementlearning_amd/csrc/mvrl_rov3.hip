@@ -186,24 +186,32 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
 #define LANE i_in
     float y[6], sp[3], path[4];
     Pid3 pid;
+    // load order as in mvrl_rov6.hip: what the turbulence gathers depend on first, everything else behind it,
+    // branch-free up to the RK4 loop so that the gathers leave before the bulk of the state is waited on
+    y[0] = ST(R3_Y + 0); y[1] = ST(R3_Y + 1);
+    int istep = unpack_int(ST(R3_ISTEP));
+    float toff = 0.f;
+    if (FLOW) toff = ST(R3_TOFF);
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < 6; k++) y[k] = ST(R3_Y + k);
+    for (int k = 2; k < 6; k++) y[k] = ST(R3_Y + k);
 #pragma unroll
     for (int k = 0; k < 3; k++) { pid.eold[k] = ST(R3_EOLD + k); pid.eint[k] = ST(R3_EINT + k); }
-    int istep = unpack_int(ST(R3_ISTEP));
-    if (io.fixed_sp) {
+    float spin[3];
+    {
+        const float* arow = io.fixed_sp ? nullptr : io.actions + (size_t)i_in * 3;
 #pragma unroll
-        for (int k = 0; k < 3; k++) sp[k] = ST(R3_SP + k);
-    } else {  // 3DoF.py:469-472
-        const float* a = io.actions + (size_t)i_in * 3;
-        sp[0] = fmaf(a[0], p->act_scale[0], y[0]);
-        sp[1] = fmaf(a[1], p->act_scale[1], y[1]);
-        sp[2] = fmaf(a[2], p->act_scale[2], y[2]);
+        for (int k = 0; k < 3; k++) spin[k] = io.fixed_sp ? ST(R3_SP + k) : arow[k];
     }
     const bool first = (istep == 0);
     istep += 1;
+    FlowTap tap;
+    if (FLOW) tap = flow_gather(fl, (float)istep * io.dt + toff, y[0], y[1]);
+#pragma unroll
+    for (int k = 0; k < 3; k++)  // 3DoF.py:469-472
+        sp[k] = io.fixed_sp ? spin[k] : fmaf(spin[k], p->act_scale[k], y[k]);
     float2 cur = make_float2(0.f, 0.f);
-    if (FLOW) cur = flow_interp_uv(fl, (float)istep * io.dt + ST(R3_TOFF), y[0], y[1]);
+    if (FLOW) cur = flow_combine(tap);
     if (first) { pid.eold[0] = sp[0] - y[0]; pid.eold[1] = sp[1] - y[1]; pid.eold[2] = angle_error(sp[2], y[2]); }
 
     const float h_s = io.dt / (float)io.n_sub;

@@ -85,6 +85,38 @@ def test_vecenv_auv_bounds_termination_and_tensors():
         e.close()
 
 
+def test_dev_stream_semantics():
+    """`*_dev` entry points run on the CALLER's stream (NULL = HIP's null stream = torch's default stream), and a later
+    host-buffer call on the same handle is ordered behind them without an explicit synchronise (include/mvrl.h)."""
+    from marinevehiclereinforcementlearning_amd._lib import MvrlError
+    n = 1 << 18
+    a, b = (MarineVecEnv("rov6", n, seed=21) for _ in range(2))
+    a.reset_tensors(); b.reset_tensors()
+    act = torch.rand((6, n, 6), device="cuda") * 2 - 1
+    side = torch.cuda.Stream()
+    for k in range(6):
+        a.step_tensors(act[k])                       # torch's default stream
+    sa = a.get_state()                               # host-buffer call right behind: no torch.cuda.synchronize()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                    # the same steps on a non-default stream
+        for k in range(6):
+            ob, _, _ = b.step_tensors(act[k])
+        # torch work queued on that stream sees the kernel's output (same-stream ordering)
+        chk = ob.clone()
+    sb = b.get_state()
+    assert np.array_equal(sa, sb)
+    side.synchronize()
+    assert torch.equal(chk, ob)
+    # mixing the asynchronous host path with the device path is refused instead of racing
+    a.handle.step_async(np.zeros((n, 6), np.float32))
+    with pytest.raises(MvrlError):
+        a.step_tensors(act[0])
+    a.handle.step_wait()
+    a.step_tensors(act[0])
+    for e in (a, b):
+        e.close()
+
+
 def test_sharded_zero_copy_gather_message():
     """Two shards (env_offset = global ids) stepping straight into their gather messages == the unsharded batch, bit for
     bit: the step kernel's out= path, OutputGather's planar message and the global-id keyed RNG (distributed.py)."""

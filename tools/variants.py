@@ -11,29 +11,20 @@ sys.path.insert(0, REPO)
 OUT = os.path.join(REPO, "variants_build")  # *.so is git-ignored; gpurun_out/ does not travel to the GPU box
 VARIANTS = {
     "base": dict(extra=[], drop=()),
+    # profiling build: per-wave s_memtime stamps at the phase boundaries of the 6-DoF step kernel (tools/stamp_probe.py)
     "stamp": dict(extra=["-DMVRL_STAMP"], drop=()),
-    "novs": dict(extra=["-DMVRL_NO_VGPR_SCALARS"], drop=()),
-    "ilp": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp"], drop=()),
-    "ilpw3": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-DMVRL_MIN_WAVES=3"], drop=()),
-    "auvscatter": dict(extra=["-DMVRL_AUV_LDS_OBS=0"], drop=()),
-    "lds0": dict(extra=["-DMVRL_LDS_STATE=0"], drop=()),
-    "w4lds0": dict(extra=["-DMVRL_LDS_STATE=0", "-DMVRL_MIN_WAVES=4"], drop=()),
+    # ablations of choices the default build makes
+    "novs": dict(extra=["-DMVRL_NO_VGPR_SCALARS"], drop=()),          # RK step sizes left in SGPRs
+    "auvscatter": dict(extra=["-DMVRL_AUV_LDS_OBS=0"], drop=()),      # AuvEnv observations stored row-per-lane
     "blk256": dict(extra=["-DMVRL_STEP_BLOCK=256"], drop=()),
-    "w4blk256": dict(extra=["-DMVRL_STEP_BLOCK=256", "-DMVRL_MIN_WAVES=4"], drop=()),
-    "blk64": dict(extra=["-DMVRL_BLOCK=64"], drop=()),
-    "blk128": dict(extra=["-DMVRL_BLOCK=128"], drop=()),
-    "blk512": dict(extra=["-DMVRL_BLOCK=512"], drop=()),
     "slp": dict(extra=[], drop=("-fno-slp-vectorize",)),
+    "nofast": dict(extra=[], drop=("-ffast-math",)),
+    "native": dict(extra=["-DMVRL_NATIVE_TRIG"], drop=()),            # hardware v_sin/v_cos (1e-6 absolute accuracy)
     "w2": dict(extra=["-DMVRL_MIN_WAVES=2"], drop=()),
     "w3": dict(extra=["-DMVRL_MIN_WAVES=3"], drop=()),
-    "w4": dict(extra=["-DMVRL_MIN_WAVES=4"], drop=()),
-    "w2slp": dict(extra=["-DMVRL_MIN_WAVES=2"], drop=("-fno-slp-vectorize",)),
-    "fast": dict(extra=["-ffast-math"], drop=()),
-    "fastnative": dict(extra=["-ffast-math", "-DMVRL_NATIVE_TRIG"], drop=()),
-    "w4fast": dict(extra=["-ffast-math", "-DMVRL_MIN_WAVES=4"], drop=()),
-    "native": dict(extra=["-DMVRL_NATIVE_TRIG"], drop=()),
-    "finite": dict(extra=["-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"], drop=()),
-    "w3finite": dict(extra=["-DMVRL_MIN_WAVES=3", "-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"], drop=()),
+    "w4": dict(extra=["-DMVRL_MIN_WAVES=4"], drop=()),                # spills
+    "ilp": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp"], drop=()),
+    "ilpw3": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-DMVRL_MIN_WAVES=3"], drop=()),
 }
 
 
