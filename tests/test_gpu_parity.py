@@ -266,6 +266,124 @@ def test_rov6_with_turbulence_vs_oracle(oracle_mod, base_flow):
         h.close()
 
 
+def test_config_fuzz_vs_oracle(oracle_mod, base_flow):
+    """Seeded sweep over combinations no other test pins: ragged batch sizes (1, 63, 65, 257, 1000: partial tail waves),
+    odd sub-step counts, other dt, fixed set-point x turbulence x controller placement x kernel flavour.  Every case is
+    compared with the fp64 oracle for 8 env steps; tolerance 1e-5 with the usual outlier-lane accounting."""
+    from oracle import flow_ref
+    base, bdx, bdy = base_flow[:3]
+    fd, fdx, fdy, fdt = flow_ref.scale(base, bdx, bdy, BASE_DT, 11., 1., 2.)
+    uv = np.ascontiguousarray(fd[..., :2])
+    rng = np.random.default_rng(2024)
+    sizes = [1, 63, 65, 257, 1000]
+    flavours = {6: [None, dict(m=12.0, Xuu=-19.0), dict(CG=[0.01, -0.015, 0.04], Yr=-0.3)],
+                3: [None, dict(m=12.0, CG=[0.01, 0.02, 0.02], Yr=-0.2)]}
+    report = []
+    for case in range(24):
+        dof = 6 if case % 2 == 0 else 3
+        n = sizes[case % len(sizes)]
+        dt = float(rng.choice([0.1, 0.2]))
+        # h = dt / n_sub stays <= 0.1 s: at h = 0.2 the closed loop is outside RK4's stability region (DESIGN.md 1) and
+        # amplifies the fp32 round-off of ANY implementation, which is not a parity statement
+        n_sub = int(rng.choice([1, 2, 3, 4] if dt == 0.1 else [2, 3, 4, 5]))
+        mode = int(rng.choice([P.CTRL_FAITHFUL, P.CTRL_ZOH]))
+        fixed = bool(rng.integers(0, 2))
+        use_flow = bool(rng.integers(0, 2))
+        over = flavours[dof][int(rng.integers(0, len(flavours[dof])))]
+        kw = {}
+        if over is not None:
+            kw["rov6" if dof == 6 else "rov3"] = (P.rov6_params if dof == 6 else P.rov3_params)(**over)
+        steps = 8
+        init, actions = random_rov_batch(dof, n, steps, 1000 + case)
+        npos = 3 if dof == 6 else 2
+        if use_flow:
+            init[:, :2] *= 0.05                          # keep the vehicles inside the table
+            init[:, npos:npos + 2] *= 0.05
+        cfg = P.make_config("rov6" if dof == 6 else "rov3", n, dt=dt, n_substeps=n_sub, control_mode=mode,
+                            fixed_setpoint=fixed, auto_reset=False, max_steps=10 ** 9, use_flow=use_flow, **kw)
+        h = _lib.Handle(cfg)
+        if use_flow:
+            h.set_flow(uv.astype(np.float32), fdt, fdx, fdy)
+        h.reset(init=init)
+        toff = (rng.random(n) * 2.0).astype(np.float32)
+        st = h.get_state()
+        st[-2] = toff
+        h.set_state(st)
+        env = oracle_mod.OracleRovEnv(dof, n, "f64", dt=dt, n_substeps=n_sub, control_mode=mode, fixed_setpoint=fixed,
+                                      max_steps=10 ** 9, flow=oracle_mod.FlowTable(uv, fdt, fdx, fdy) if use_flow else None,
+                                      **kw)
+        env.reset(init.astype(np.float64), toffset=toff)
+        ang = [3, 4, 5] if dof == 6 else [2]
+        bad = np.zeros(n, bool)
+        med = 0.0
+        for k in range(steps):
+            o_ref, _, _ = env.step(actions[k].astype(np.float64))
+            o_gpu, _, _ = h.step(None if fixed else actions[k])
+            e = circ_err(h.get_state()[: 2 * dof].T, env.y, ang).max(axis=1)
+            bad |= e > TOL
+            med = max(med, float(np.median(e)))
+            good = ~bad
+            assert max_scaled_err(o_gpu[good], o_ref[good]) < 2 * TOL, (case, k)
+        report.append((case, dof, n, n_sub, dt, mode, fixed, use_flow, h.variant, int(bad.sum()), med))
+        assert bad.sum() <= max(1, int(0.02 * n)), report[-1]
+        assert med < 3e-6, report[-1]
+        h.close()
+    for r in report:
+        print("fuzz case %2d dof %d n %4d n_sub %d dt %.1f mode %d fixed %d flow %d %-28s outliers %d median %.1e" % r)
+    assert len({r[8] for r in report}) >= 6      # the sweep actually reached many kernel instances
+
+
+@pytest.mark.parametrize("cyl", [False, True])
+def test_auv_ragged_batches_vs_oracle(oracle_mod, base_flow, cyl):
+    """AuvEnv / AuvEnvCyl batches of ragged size (full waves through the LDS-transposed observation store, partial
+    tail waves through the row-per-lane store) against the fp64 oracle: observations, rewards, done flags, poses."""
+    from oracle import flow_ref
+    base, bdx, bdy = base_flow[:3]
+    fd, dx, dy, dt = flow_ref.scale(base, bdx, bdy, BASE_DT, 11., 1., 2.)
+    uv = np.ascontiguousarray(fd[..., :2])
+    auv = P.auv_params(noiseMagCoeffs=0.1, noiseMagActuation=0.1, cyl=cyl)
+    for n in (1, 65, 257, 1000):
+        rng = np.random.default_rng(50 + n)
+        init = np.zeros((n, 16))
+        init[:, :2] = (rng.random((n, 2)) - 0.5) * (1.5 if cyl else 0.5)
+        init[:, 2] = rng.random(n) * 2 * np.pi
+        init[:, 3] = rng.integers(0, 5, n) if cyl else rng.random(n) * 2 * np.pi
+        init[:, 4] = rng.random(n) * 2.0
+        init[:, 5:] = 1.0 + 0.05 - rng.random((n, 11)) * 0.1
+        steps = 40
+        actions = rng.uniform(-1, 1, size=(steps, n, 3)).astype(np.float32)
+        h = _lib.Handle(P.make_config("auv", n, dt=0.02, auto_reset=False, max_steps=30, use_flow=True, auv=auv))
+        h.set_flow(uv.astype(np.float32), dt, dx, dy)
+        env = oracle_mod.OracleAuvEnv(n, "f64", dt=0.02, max_steps=30, flow=oracle_mod.FlowTable(uv, dt, dx, dy), auv=auv)
+        o_gpu = h.reset(init=init.astype(np.float32))
+        o_ref = env.reset(init.astype(np.float32).astype(np.float64))
+        assert max_scaled_err(o_gpu, o_ref) < TOL
+        alive = np.ones(n, bool)
+        for k in range(steps):
+            o_ref, r_ref, d_ref = env.step(actions[k].astype(np.float64))
+            o_gpu, r_gpu, d_gpu = h.step(actions[k])
+            st = h.get_state()
+            pose = st[:6].T
+            # a lane within fp32 resolution of the +-bounds / way-point threshold may legitimately fall on the other side
+            near = alive & ((d_gpu != 0) != (d_ref != 0))
+            assert near.sum() <= max(1, n // 200), (n, k, int(near.sum()))
+            alive &= ~near
+            a = alive
+            assert np.array_equal((d_gpu[a] != 0), (d_ref[a] != 0))
+            assert circ_err(pose[a], env.pose[a], [2]).max(initial=0.0) < TOL, (n, k)
+            # the "V0" observation of AuvEnvCyl scales error CHANGES by 1/0.025 and 1/(2 deg): 40 x the fp32 resolution
+            # of a pose near 2 (2.4e-7) and of an angle near 2 pi (4.8e-7), two roundings each
+            assert np.max(np.abs(o_gpu[a] - o_ref[a]), initial=0.0) < (1.5e-4 if cyl else 3e-5), (n, k)
+            assert np.max(np.abs(r_gpu[a] - r_ref[a]) / np.maximum(1.0, np.abs(r_ref[a])), initial=0.0) < 3e-5, (n, k)
+            if cyl:
+                iwp = st[-1].view(np.int32)
+                switched = alive & (iwp != env.iwp)
+                assert switched.sum() <= max(1, n // 200)
+                alive &= ~switched
+        assert alive.mean() > 0.98
+        h.close()
+
+
 # ---- env API semantics ---------------------------------------------------------------------------------
 def test_auto_reset_terminal_obs_and_rng_shard_invariance():
     n, max_steps = 512, 5
