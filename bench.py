@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--graph", action="store_true", help="replay the RING step launches from a captured HIP graph "
+                    "(pays off when the batch is small enough to be launch-bound: DESIGN.md section 5)")
     ap.add_argument("--gather", default="root", choices=["root", "all", "none"])
     ap.add_argument("--gather-timeout", type=float, default=240.0, help="watchdog for the N > 1 gather measurement [s]")
     ap.add_argument("--n-substeps", type=int, default=4)
@@ -175,8 +177,24 @@ def main():
                 buf.add(st[0], nobs, act, rew, done)
                 st[0].copy_(nobs)
             return
+        if graph is not None and steps % RING == 0:
+            for _ in range(steps // RING):
+                graph.replay()
+            h.count_launches(steps)
+            return
         for k in range(steps):
             env.step_tensors(ring[k % RING])
+
+    graph = None
+    if args.graph and loop_objs is None:
+        # one HIP graph of RING consecutive step launches (the env's RNG position lives in its state, so a replay is
+        # exactly the next RING steps); captured on a side stream as torch requires
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=cap):
+            for k in range(RING):
+                env.step_tensors(ring[k])
 
     # ---- N > 1: gather overlapped with the next step on a side stream, outputs double-buffered ---------------
     gather = None
@@ -239,6 +257,7 @@ def main():
             "config": {"workload": wl["name"], "envs_per_gpu": n, "global_envs": world * n, "dt": 0.02 if wl["model"].startswith("auv") else 0.2,
                        "n_substeps": args.n_substeps, "control_mode": args.control_mode, "episode_len": 250,
                        "kernel": env.variant, "actions": f"ring of {RING} pre-generated uniform(-1,1) batches in HBM",
+                       "launch": "hip graph of %d steps" % RING if graph is not None else "one launch per step",
                        "collective_in_value": "none: shards are independent, outputs stay in each rank's HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

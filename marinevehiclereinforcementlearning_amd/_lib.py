@@ -237,7 +237,12 @@ class Handle:
 
     def step_counter(self, state=None):
         st = self.get_state() if state is None else state
-        return st[-1].view(self.itype)
+        return st[P.STATE_PLANES[self.model]["istep"]].view(self.itype)
+
+    def episode_counter(self, state=None):
+        """Number of resets each env has gone through = the counter of its Philox stream."""
+        st = self.get_state() if state is None else state
+        return st[P.STATE_PLANES[self.model]["episode"]].view(self.itype)
 
     def enable_aux(self, on=True):
         check(self.lib.mvrl_enable_aux(self.h, 1 if on else 0), self.h)
@@ -265,13 +270,19 @@ class Handle:
     def fill_uniform_dev(self, ptr, n, seed, counter, lo=-1.0, hi=1.0, stream=None):
         check(self.lib.mvrl_fill_uniform_dev(self.h, ptr, n, seed, counter, lo, hi, stream), self.h)
 
+    def count_launches(self, k):
+        """Step launches replayed from a captured graph do not pass through the library: account for them here so
+        that timing_end() reports the right launch count."""
+        self._graph_launches = getattr(self, "_graph_launches", 0) + int(k)
+
     def timing_begin(self, stream=None):
+        self._graph_launches = 0
         check(self.lib.mvrl_timing_begin(self.h, stream), self.h)
 
     def timing_end(self, stream=None):
         ms, nl = C.c_float(), C.c_int64()
         check(self.lib.mvrl_timing_end(self.h, stream, C.byref(ms), C.byref(nl)), self.h)
-        return ms.value, nl.value
+        return ms.value, nl.value + getattr(self, "_graph_launches", 0)
 
     def dev_alloc(self, nbytes):
         p = C.c_void_p()

@@ -17,7 +17,8 @@ enum {
     AV_MULT = 10,   // m I Xuu Yvv Nrr Xu Yv Nr Xact Yact Nact  (verySimpleAuv.py:222-229)
     AV_TOFF = 21, AV_HIST = 22, AV_ISTEP = 52,
     AV_IWP = 53,    // AuvEnvCyl: way-point index (integer bit pattern); survives reset() like the reference's self.iWp
-    AV_WORDS = 54
+    AV_EPISODE = 54,  // number of resets of this env = counter of its Philox stream (see mvrl_rov6.hip)
+    AV_WORDS = 55
 };
 
 // dataToState "V3" (verySimpleAuv.py:201-212); positionTarget = 0 (:241)
@@ -170,7 +171,9 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
             for (int q = 0; q < 11; q++) io.term_obs[(size_t)i * 11 + q] = o[q];
         }
         float v[16];
-        random_init_auv(p, io.seed, io.env_offset + (int64_t)i, io.epoch, fl.t_quarter, v);
+        const int episode = unpack_int(ST(AV_EPISODE)) + 1;
+        ST(AV_EPISODE) = pack_int(episode);
+        random_init_auv(p, io.seed, io.env_offset + (int64_t)i, (uint32_t)episode, fl.t_quarter, v);
         x = v[0]; y = v[1]; psi = v[2]; vx = 0.f; vy = 0.f; r = 0.f;
         if (!cyl) tgt = v[3];   // AuvEnvCyl: the target stays waypoints[iWp] - iWp is not reset (_cyl.py:41,141-142)
         ST(AV_TOFF) = v[4];
@@ -219,17 +222,19 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
 
 __global__ __launch_bounds__(MVRL_BLOCK) void auv_reset_kernel(const AuvDev p, float* state, int64_t n, const uint8_t* mask,
                                                                const float* init, float* obs, uint64_t seed,
-                                                               int64_t env_offset, uint32_t epoch, float t_quarter) {
+                                                               int64_t env_offset, float t_quarter) {
     const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
     if (i >= n) return;
     if (mask && !mask[i]) return;
     float* st = state + i;
+    const int episode = unpack_int(st[AV_EPISODE * n]) + 1;
+    st[AV_EPISODE * n] = pack_int(episode);
     float v[16];
     if (init) {
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = init[i * 16 + q];
     } else {
-        random_init_auv(p, seed, env_offset + i, epoch, t_quarter, v);
+        random_init_auv(p, seed, env_offset + i, (uint32_t)episode, t_quarter, v);
     }
     const float x = v[0], y = v[1], psi = v[2];
     float tgt = v[3], tx = 0.f, ty = 0.f;
@@ -267,9 +272,9 @@ hipError_t launch_auv_step(const AuvDev& p, const StepIO& io, const FlowDev& fl,
 }
 
 hipError_t launch_auv_reset(const AuvDev& p, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
-                            uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream) {
+                            uint64_t seed, int64_t env_offset, float t_quarter, hipStream_t stream) {
     dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
-    hipLaunchKernelGGL(auv_reset_kernel, grid, block, 0, stream, p, state, n, mask, init, obs, seed, env_offset, epoch,
+    hipLaunchKernelGGL(auv_reset_kernel, grid, block, 0, stream, p, state, n, mask, init, obs, seed, env_offset,
                        t_quarter);
     return hipGetLastError();
 }

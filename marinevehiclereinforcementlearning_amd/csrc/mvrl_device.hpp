@@ -113,7 +113,7 @@ __device__ __forceinline__ float pack_int(int i) { return __int_as_float(i); }
 #endif
 
 // ---- Philox4x32-10 counter-based RNG (Salmon et al. 2011) -----------------------------------------
-// Streams are keyed by (seed) and counted by (global env id, epoch, slot) so results do not depend on how
+// Streams are keyed by (seed) and counted by (global env id, the env's episode counter, slot) so results do not depend on how
 // the batch is sharded over GPUs.
 struct Philox4 {
     uint32_t v[4];
@@ -288,7 +288,6 @@ struct StepIO {
     int64_t n;
     int64_t env_offset;
     uint64_t seed;
-    uint32_t epoch;         // RNG epoch of this call
     int n_sub;
     int max_steps;
     int fixed_sp;

@@ -7,16 +7,16 @@ namespace mvrl {
 hipError_t launch_rov6_step(const Rov6Dev* p_dev, const StepIO& io, const FlowDev& fl, bool baked, bool sym, bool zoh,
                             bool flow, bool rk45, hipStream_t stream);
 hipError_t launch_rov6_reset(const Rov6Dev* p_dev, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
-                             uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream);
+                             uint64_t seed, int64_t env_offset, float t_quarter, hipStream_t stream);
 
 hipError_t launch_rov3_step(const Rov3Dev* p_dev, const StepIO& io, const FlowDev& fl, bool baked, bool zoh, bool flow,
                             bool rk45, hipStream_t stream);
 hipError_t launch_rov3_reset(const Rov3Dev* p_dev, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
-                             uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream);
+                             uint64_t seed, int64_t env_offset, float t_quarter, hipStream_t stream);
 
 hipError_t launch_auv_step(const AuvDev& p, const StepIO& io, const FlowDev& fl, bool flow, hipStream_t stream);
 hipError_t launch_auv_reset(const AuvDev& p, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
-                            uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream);
+                            uint64_t seed, int64_t env_offset, float t_quarter, hipStream_t stream);
 
 hipError_t launch_flow_interp(const float* table, int n_t, int n_y, int n_x, int n_comp, float inv_dt, float inv_dx,
                               float inv_dy, const float* t, const float* x, const float* y, int64_t n, float* out,
@@ -33,6 +33,6 @@ hipError_t launch_replay_add_sym(const float* obs, const float* next_obs, const 
 hipError_t launch_fill_uniform(float* dst, int64_t n, uint64_t seed, uint64_t counter, float lo, float hi,
                                hipStream_t stream);
 
-enum { R6_WORDS_ = 40, R3_WORDS_ = 23, AUV_WORDS_ = 54 };
+enum { R6_WORDS_ = 41, R3_WORDS_ = 24, AUV_WORDS_ = 55 };
 
 }  // namespace mvrl

@@ -129,8 +129,8 @@ __device__ __forceinline__ void random_init3(uint64_t seed, int64_t gid, uint32_
     toffset = u01(r1.v[1]) * t_quarter;
 }
 
-enum { R3_Y = 0, R3_EOLD = 6, R3_EINT = 9, R3_SP = 12, R3_PATH = 15, R3_TOLD = 19, R3_TIME = 20, R3_TOFF = 21, R3_ISTEP = 22,
-       R3_WORDS = 23 };
+enum { R3_Y = 0, R3_EOLD = 6, R3_EINT = 9, R3_SP = 12, R3_PATH = 15, R3_EPISODE = 19 /* see mvrl_rov6.hip */, R3_TOLD = 20, R3_TIME = 21,
+       R3_TOFF = 22, R3_ISTEP = 23, R3_WORDS = 24 };
 
 #if MVRL_F64
 // BlueROV2Heavy3DoF.derivs (3DoF.py:128-296) with run-time t - tOld, as the RHS functor of the adaptive solver
@@ -300,9 +300,11 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
 #pragma unroll
             for (int q = 0; q < 5; q++) io.term_obs[(size_t)i * 5 + q] = o[q];
         }
+        const int episode = unpack_int(ST(R3_EPISODE)) + 1;
+        ST(R3_EPISODE) = pack_int(episode);
         if (!io.fixed_sp) {
             float heading, toff;
-            random_init3(io.seed, io.env_offset + (int64_t)i, io.epoch, fl.t_quarter, path, heading, toff);
+            random_init3(io.seed, io.env_offset + (int64_t)i, (uint32_t)episode, fl.t_quarter, path, heading, toff);
 #pragma unroll
             for (int q = 0; q < 4; q++) ST(R3_PATH + q) = path[q];
             ST(R3_TOFF) = toff;
@@ -332,19 +334,21 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
 
 __global__ __launch_bounds__(MVRL_BLOCK) void rov3_reset_kernel(const Rov3Dev* __restrict__ pg, float* state, int64_t n, const uint8_t* mask,
                                                                 const float* init, float* obs, uint64_t seed,
-                                                                int64_t env_offset, uint32_t epoch, float t_quarter) {
+                                                                int64_t env_offset, float t_quarter) {
     const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
     if (i >= n) return;
     if (mask && !mask[i]) return;
     const CP3 p = as_const(pg);
     float* st = state + i;
+    const int episode = unpack_int(st[R3_EPISODE * n]) + 1;
+    st[R3_EPISODE * n] = pack_int(episode);
     float path[4], sp[3], y[6] = {0, 0, 0, 0, 0, 0}, toff = 0.f;
     if (init) {
 #pragma unroll
         for (int q = 0; q < 4; q++) path[q] = init[i * 5 + q];
         sp[2] = init[i * 5 + 4];
     } else {
-        random_init3(seed, env_offset + i, epoch, t_quarter, path, sp[2], toff);
+        random_init3(seed, env_offset + i, (uint32_t)episode, t_quarter, path, sp[2], toff);
     }
     sp[0] = path[0]; sp[1] = path[1];
 #pragma unroll
@@ -388,9 +392,9 @@ hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& f
 }
 
 hipError_t launch_rov3_reset(const Rov3Dev* p, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
-                             uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream) {
+                             uint64_t seed, int64_t env_offset, float t_quarter, hipStream_t stream) {
     dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
-    hipLaunchKernelGGL(rov3_reset_kernel, grid, block, 0, stream, p, state, n, mask, init, obs, seed, env_offset, epoch,
+    hipLaunchKernelGGL(rov3_reset_kernel, grid, block, 0, stream, p, state, n, mask, init, obs, seed, env_offset,
                        t_quarter);
     return hipGetLastError();
 }

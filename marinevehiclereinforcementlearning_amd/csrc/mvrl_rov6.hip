@@ -323,8 +323,11 @@ __device__ __forceinline__ void random_init6(uint64_t seed, int64_t gid, uint32_
 
 // SoA planes.  TOLD/TIME (the PID's tOld and the env's accumulated time, 6DoF.py:40,534) are only touched by the
 // RK45 integrator: under the RK4 harness t - tOld is a compile-time pattern.
-enum { R6_Y = 0, R6_EOLD = 12, R6_EINT = 18, R6_SP = 24, R6_PATH = 30, R6_TOLD = 36, R6_TIME = 37, R6_TOFF = 38, R6_ISTEP = 39,
-       R6_WORDS = 40 };
+// EPISODE counts the resets of this env: it is the counter of the env's Philox stream, so a random reset depends only on
+// (seed, global env id, how many episodes this env has started) - not on how many launches the handle has issued, which
+// also makes the launches replayable from a captured HIP graph.
+enum { R6_Y = 0, R6_EOLD = 12, R6_EINT = 18, R6_SP = 24, R6_PATH = 30, R6_EPISODE = 36, R6_TOLD = 37, R6_TIME = 38, R6_TOFF = 39,
+       R6_ISTEP = 40, R6_WORDS = 41 };
 
 #if MVRL_F64
 // PID with run-time t - tOld, for the adaptive integrator (6DoF.py:43-73 verbatim)
@@ -550,13 +553,15 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
             for (int q = 0; q < 9; q++) io.term_obs[(size_t)i * 9 + q] = o[q];
         }
         float ang[3], toff;
+        const int episode = unpack_int(ST(R6_EPISODE)) + 1;
+        ST(R6_EPISODE) = pack_int(episode);
         if (io.fixed_sp) {
             // reset(initialSetpoint=sp) keeps the set-point: path/sp stay (6DoF.py:500-511)
 #pragma unroll
             for (int q = 0; q < 3; q++) { ang[q] = sp[3 + q]; }
             toff = FLOW ? ST(R6_TOFF) : 0.f;
         } else {
-            random_init6(io.seed, io.env_offset + (int64_t)i, io.epoch, fl.t_quarter, path, ang, toff);
+            random_init6(io.seed, io.env_offset + (int64_t)i, (uint32_t)episode, fl.t_quarter, path, ang, toff);
 #pragma unroll
             for (int q = 0; q < 6; q++) ST(R6_PATH + q) = path[q];
             ST(R6_TOFF) = toff;
@@ -596,12 +601,14 @@ extern "C" int mvrl_debug_stamps(unsigned long long* dst, size_t n_words) {
 // reset (6DoF.py:485-529): mask/init may be null.
 __global__ __launch_bounds__(MVRL_BLOCK) void rov6_reset_kernel(const Rov6Dev* __restrict__ pg, float* state, int64_t n, const uint8_t* mask,
                                                                 const float* init, float* obs, uint64_t seed,
-                                                                int64_t env_offset, uint32_t epoch, float t_quarter) {
+                                                                int64_t env_offset, float t_quarter) {
     const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
     if (i >= n) return;
     if (mask && !mask[i]) return;
     const CP6 p = as_const(pg);
     float* st = state + i;
+    const int episode = unpack_int(st[R6_EPISODE * n]) + 1;
+    st[R6_EPISODE * n] = pack_int(episode);
     float path[6], sp[6], y[12], toff = 0.f;
     if (init) {
 #pragma unroll
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_reset_kernel(const Rov6Dev* _
         sp[3] = init[i * 9 + 6]; sp[4] = init[i * 9 + 7]; sp[5] = init[i * 9 + 8];
     } else {
         float ang[3];
-        random_init6(seed, env_offset + i, epoch, t_quarter, path, ang, toff);
+        random_init6(seed, env_offset + i, (uint32_t)episode, t_quarter, path, ang, toff);
         sp[0] = path[0]; sp[1] = path[1]; sp[2] = path[2]; sp[3] = ang[0]; sp[4] = ang[1]; sp[5] = ang[2];
     }
 #pragma unroll
@@ -663,10 +670,9 @@ hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& f
 }
 
 hipError_t launch_rov6_reset(const Rov6Dev* p, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
-                             uint64_t seed, int64_t env_offset, uint32_t epoch, float t_quarter, hipStream_t stream) {
+                             uint64_t seed, int64_t env_offset, float t_quarter, hipStream_t stream) {
     dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
-    hipLaunchKernelGGL(rov6_reset_kernel, grid, block, 0, stream, p, state, n, mask, init, obs, seed, env_offset, epoch,
-                       t_quarter);
+    hipLaunchKernelGGL(rov6_reset_kernel, grid, block, 0, stream, p, state, n, mask, init, obs, seed, env_offset, t_quarter);
     return hipGetLastError();
 }
 

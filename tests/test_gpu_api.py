@@ -85,6 +85,43 @@ def test_vecenv_auv_bounds_termination_and_tensors():
         e.close()
 
 
+def test_hip_graph_replay_equals_plain_stepping():
+    """A sequence of mvrl_step_dev launches captured into a HIP graph (torch.cuda.CUDAGraph) and replayed is bit-identical
+    to issuing the launches one by one - including the RANDOM auto-resets in between, because the Philox counter of an
+    env is its own episode number (state plane `episode`), not a host-side launch counter baked into the capture."""
+    from marinevehiclereinforcementlearning_amd import params as P
+    n, R, reps = 3000, 4, 6
+    kw = dict(seed=9, maxSteps=5)                     # episodes of 5 steps: 24 steps cross four random resets per env
+    a, b = MarineVecEnv("rov3", n, **kw), MarineVecEnv("rov3", n, **kw)
+    a.reset_tensors(); b.reset_tensors()
+    act = torch.rand((R, n, 3), device="cuda") * 2 - 1
+    outs_a = []
+    for k in range(R * reps):
+        o, r, d = a.step_tensors(act[k % R])
+        outs_a.append((o.clone(), d.clone()))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    ob = torch.empty((R, n, 5), device="cuda"); rb = torch.empty((R, n), device="cuda")
+    db = torch.empty((R, n), dtype=torch.uint8, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    st0 = b.get_state()
+    with torch.cuda.graph(g, stream=side):
+        for k in range(R):
+            b.step_tensors(act[k], out=(ob[k], rb[k], db[k]))
+    b.set_state(st0)                                   # capture executes nothing, but be explicit about the start state
+    for rep in range(reps):
+        g.replay()
+        torch.cuda.synchronize()
+        for k in range(R):
+            o_ref, d_ref = outs_a[rep * R + k]
+            assert torch.equal(ob[k], o_ref) and torch.equal(db[k], d_ref), (rep, k)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa, sb)
+    ep = sa[P.STATE_PLANES[P.MODEL_ROV3]["episode"]].view(np.int32)
+    assert np.all(ep == 1 + (R * reps) // 5)           # reset() + one auto-reset every 5 steps
+    a.close(); b.close()
+
+
 def test_dev_stream_semantics():
     """`*_dev` entry points run on the CALLER's stream (NULL = HIP's null stream = torch's default stream), and a later
     host-buffer call on the same handle is ordered behind them without an explicit synchronise (include/mvrl.h)."""

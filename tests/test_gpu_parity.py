@@ -376,7 +376,7 @@ def test_auv_ragged_batches_vs_oracle(oracle_mod, base_flow, cyl):
             assert np.max(np.abs(o_gpu[a] - o_ref[a]), initial=0.0) < (1.5e-4 if cyl else 3e-5), (n, k)
             assert np.max(np.abs(r_gpu[a] - r_ref[a]) / np.maximum(1.0, np.abs(r_ref[a])), initial=0.0) < 3e-5, (n, k)
             if cyl:
-                iwp = st[-1].view(np.int32)
+                iwp = st[P.STATE_PLANES[P.MODEL_AUV]["iwp"]].view(np.int32)
                 switched = alive & (iwp != env.iwp)
                 assert switched.sum() <= max(1, n // 200)
                 alive &= ~switched
