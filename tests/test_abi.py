@@ -64,7 +64,7 @@ def test_bad_config_is_rejected(lib):
     assert b"ABI" in lib.mvrl_last_error(None)
     cfg = P.make_config("rov6", 0)
     assert lib.mvrl_create(C.byref(cfg), C.byref(h)) == -1
-    cfg = P.make_config("rov6", 40_000_000)  # 38 words * n >= 2^30
+    cfg = P.make_config("rov6", 40_000_000)  # 41 words * n * 4 B >= 2^32
     assert lib.mvrl_create(C.byref(cfg), C.byref(h)) == -1
     cfg = P.make_config("rov3", 8, n_substeps=0)
     assert lib.mvrl_create(C.byref(cfg), C.byref(h)) == -1
