@@ -195,8 +195,11 @@ def test_gather_message_through_rccl_single_rank():
     import torch.distributed as dist
     from marinevehiclereinforcementlearning_amd import distributed as D
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    except Exception as e:  # noqa: BLE001 - a box without a usable RCCL bootstrap must not take the parity suite down
+        pytest.skip(f"RCCL process group could not be created here: {e!r}")
     try:
         env = MarineVecEnv("rov6", 2048, seed=3)
         env.reset_tensors()
