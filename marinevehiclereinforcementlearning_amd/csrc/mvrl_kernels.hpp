@@ -24,8 +24,8 @@ hipError_t launch_flow_interp(const float* table, int n_t, int n_y, int n_x, int
 hipError_t launch_flow_reconstruct(const float* modes_re, const float* modes_im, const float* coeffs_re,
                                    const float* coeffs_im, const float* ltm, int n_space3, int n_modes, int n_t,
                                    const float* scale_mul, const float* scale_add, float* out, hipStream_t stream);
-hipError_t launch_pd_policy(const float* obs, int obs_dim, float* old_obs, uint8_t* has_old, float* actions, int64_t n, float dt,
-                            const float* P, const float* D, float noise_sigma, uint64_t seed, uint32_t epoch, hipStream_t stream);
+hipError_t launch_pd_policy(const float* obs, int obs_dim, float* old_obs, uint32_t* calls, float* actions, int64_t n, float dt,
+                            const float* P, const float* D, float noise_sigma, uint64_t seed, hipStream_t stream);
 hipError_t launch_los_policy(const float* obs, int obs_dim, float* actions, int64_t n, float Rnav, hipStream_t stream);
 hipError_t launch_replay_add_sym(const float* obs, const float* next_obs, const float* act, const float* rew, const uint8_t* done,
                                  const uint8_t* timeout, int64_t n_envs, float* b_obs, float* b_next, float* b_act, float* b_rew,

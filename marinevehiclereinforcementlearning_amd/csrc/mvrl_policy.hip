@@ -11,14 +11,16 @@ namespace mvrl {
 // With noise_sigma > 0 a normal deviate is added before the second clip (verySimpleAuv.py:44-45); the deviates come
 // from Philox + Box-Muller, not from numpy's global generator.
 __global__ __launch_bounds__(MVRL_BLOCK) void pd_policy_kernel(const float* __restrict__ obs, int obs_dim, float* __restrict__ old_obs,
-                                                               uint8_t* __restrict__ has_old, float* __restrict__ actions,
+                                                               uint32_t* __restrict__ calls, float* __restrict__ actions,
                                                                int64_t n, float inv_dt, float p0, float p1, float p2, float d0,
-                                                               float d1, float d2, float noise_sigma, uint64_t seed,
-                                                               uint32_t epoch) {
+                                                               float d1, float d2, float noise_sigma, uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float P[3] = {p0, p1, p2}, D[3] = {d0, d1, d2};
-    const bool ho = has_old[i] != 0;
+    // calls[i] = predict() calls since the last reset: "oldObs is None" on the first, and the counter of this env's noise
+    // stream (device-resident, so the launch carries nothing that changes from call to call - graph-replayable)
+    const uint32_t epoch = calls[i];
+    const bool ho = epoch != 0;
     float nz[3] = {0.f, 0.f, 0.f};
     if (noise_sigma > 0.f) {
         Philox4 r = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), epoch, 0x50444eu, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void pd_policy_kernel(const float* __re
         actions[i * 3 + k] = a;
         old_obs[i * 3 + k] = x;
     }
-    has_old[i] = 1;
+    calls[i] = epoch + 1u;
 }
 
 // lineOfSight(p0, p1, Rnav) (3DoF.py:517-581), branch for branch
@@ -84,11 +86,11 @@ __global__ __launch_bounds__(MVRL_BLOCK) void los_policy_kernel(const float* __r
     actions[i * 3 + 2] = o[4];
 }
 
-hipError_t launch_pd_policy(const float* obs, int obs_dim, float* old_obs, uint8_t* has_old, float* actions, int64_t n, float dt,
-                            const float* P, const float* D, float noise_sigma, uint64_t seed, uint32_t epoch, hipStream_t stream) {
+hipError_t launch_pd_policy(const float* obs, int obs_dim, float* old_obs, uint32_t* calls, float* actions, int64_t n, float dt,
+                            const float* P, const float* D, float noise_sigma, uint64_t seed, hipStream_t stream) {
     dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
-    hipLaunchKernelGGL(pd_policy_kernel, grid, block, 0, stream, obs, obs_dim, old_obs, has_old, actions, n, 1.0f / dt, P[0], P[1], P[2],
-                       D[0], D[1], D[2], noise_sigma, seed, epoch);
+    hipLaunchKernelGGL(pd_policy_kernel, grid, block, 0, stream, obs, obs_dim, old_obs, calls, actions, n, 1.0f / dt, P[0], P[1], P[2],
+                       D[0], D[1], D[2], noise_sigma, seed);
     return hipGetLastError();
 }
 
