@@ -198,7 +198,7 @@ def main():
 
     # ---- N > 1: gather overlapped with the next step on a side stream, outputs double-buffered ---------------
     gather = None
-    if world > 1 and args.gather != "none":
+    if world > 1 and args.gather != "none" and args.precision == "f32":   # the gather message is an fp32 format
         gather = [D.OutputGather(world * n, obs_dim, dev, mode=args.gather) for _ in range(2)]
         side = torch.cuda.Stream(device=dev)
         ev_step = [torch.cuda.Event() for _ in range(2)]
