@@ -134,6 +134,50 @@ class OutputGather:
         return self.unpack()
 
 
+class ActionScatter:
+    """The mirror of OutputGather: a consumer that lives on one rank - SB3's single process - holds the
+    action batch for ALL envs; every step rank `root` scatters the shards, one message per rank, padded to the largest
+    shard.  Replaces the pipe send of SubprocVecEnv.step_async (main_00_sbl.py:145).  `local()` is this rank's
+    contiguous [count, act_dim] view, valid until the next exchange."""
+
+    def __init__(self, n_global, act_dim, device, root=0, group=None):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.root, self.group = root, group
+        self.n_global, self.act_dim = int(n_global), int(act_dim)
+        self.ranges = [shard_range(n_global, r, self.world) for r in range(self.world)]
+        self.cmax = max(c for _, c in self.ranges)
+        self.offset, self.count = self.ranges[self.rank]
+        self.recv = torch.zeros((self.cmax, self.act_dim), dtype=torch.float32, device=device)
+        self.send = (torch.zeros((self.world, self.cmax, self.act_dim), dtype=torch.float32, device=device)
+                     if self.rank == root else None)
+
+    def bytes_per_step(self):
+        return self.world * self.cmax * self.act_dim * 4
+
+    def exchange(self, actions_global=None):
+        """root passes the [n_global, act_dim] batch (global env order); the other ranks pass nothing."""
+        if self.rank == self.root:
+            a = actions_global.reshape(self.n_global, self.act_dim)
+            for r, (o, c) in enumerate(self.ranges):
+                self.send[r, :c].copy_(a[o:o + c])
+        if not dist.is_initialized():
+            self.recv.copy_(self.send[0])
+            return self.local()
+        if self.recv.is_cuda and dist.get_backend(self.group) == "gloo":   # rehearsal path, as in OutputGather
+            buf = torch.empty(self.recv.shape, dtype=torch.float32)
+            dist.scatter(buf, scatter_list=list(self.send.cpu().unbind(0)) if self.rank == self.root else None,
+                         src=self.root, group=self.group)
+            self.recv.copy_(buf)
+            return self.local()
+        dist.scatter(self.recv, scatter_list=list(self.send.unbind(0)) if self.rank == self.root else None,
+                     src=self.root, group=self.group)
+        return self.local()
+
+    def local(self):
+        return self.recv[: self.count]
+
+
 class ShardedVecEnv:
     """A global batch of `n_global` envs split over the ranks of the process group.
 
@@ -141,12 +185,14 @@ class ShardedVecEnv:
     `step_tensors(actions) -> (obs, reward, done)` returning torch tensors on `device` (MarineVecEnv on a GPU;
     tests inject a CPU stepper).  `step(actions_local)` steps the local shard and gathers the outputs."""
 
-    def __init__(self, make_shard, n_global, obs_dim, device, gather="root", group=None):
+    def __init__(self, make_shard, n_global, obs_dim, device, gather="root", group=None, scatter_act_dim=None):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.offset, self.count = shard_range(n_global, self.rank, self.world)
         self.local = make_shard(self.offset, self.count, self.rank)
         self.gather = None if gather in (None, "none") else OutputGather(n_global, obs_dim, device, mode=gather, group=group)
+        # scatter_act_dim = act_dim: step_global() takes the FULL action batch on rank 0 and scatters it (C2)
+        self.scatter = None if scatter_act_dim is None else ActionScatter(n_global, scatter_act_dim, device, group=group)
 
     def reset(self):
         obs = self.local.reset_tensors()
@@ -155,6 +201,11 @@ class ShardedVecEnv:
         z = torch.zeros(obs.shape[0], dtype=torch.float32, device=obs.device)
         out = self.gather(obs, z, z)
         return None if out is None else out[0]
+
+    def step_global(self, actions_global=None):
+        """The single-consumer loop (SB3 on rank 0): rank 0 passes actions for ALL envs, the other ranks None; shards are
+        scattered, stepped, and the outputs gathered back - two collectives per step."""
+        return self.step(self.scatter.exchange(actions_global))
 
     def step(self, actions_local):
         if self.gather is None:

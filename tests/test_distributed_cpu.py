@@ -46,28 +46,32 @@ class OracleShard:
         return out
 
 
-def worker(rank, world, port, n_global, mode, q, inplace=False):
+def worker(rank, world, port, n_global, mode, q, inplace=False, scatter=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, w, _ = D.init_from_env("gloo")
     assert (r, w) == (rank, world)
-    env = D.ShardedVecEnv(lambda off, cnt, rk: OracleShard(off, cnt, n_global, inplace), n_global, 9, torch.device("cpu"), gather=mode)
+    env = D.ShardedVecEnv(lambda off, cnt, rk: OracleShard(off, cnt, n_global, inplace), n_global, 9, torch.device("cpu"), gather=mode,
+                          scatter_act_dim=6 if scatter else None)
     acts = torch.from_numpy(np.random.default_rng(9).uniform(-1, 1, size=(4, n_global, 6))).float()
     def keep(x):  # gathered outputs are views into the receive buffer, valid until the next call
         return None if x is None else (x.clone() if torch.is_tensor(x) else tuple(t.clone() for t in x))
     outs = [keep(env.reset())]
     for s in range(4):
-        outs.append(keep(env.step(acts[s, env.offset:env.offset + env.count])))
+        if scatter:   # only rank 0 knows the actions (the SB3 process); the shards arrive by dist.scatter
+            outs.append(keep(env.step_global(acts[s] if rank == 0 else None)))
+        else:
+            outs.append(keep(env.step(acts[s, env.offset:env.offset + env.count])))
     if rank == 0 or mode == "all":
         q.put((rank, outs[0].numpy().copy(), [tuple(t.numpy().copy() for t in o) for o in outs[1:]]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def run_world(n_global, mode, world=2, inplace=False):
+def run_world(n_global, mode, world=2, inplace=False, scatter=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, n_global, mode, q, inplace)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, n_global, mode, q, inplace, scatter)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world if mode == "all" else 1)]
@@ -105,6 +109,23 @@ def test_two_rank_gather_equals_single_process(n_global, mode, inplace):
             assert np.array_equal(got[s][0], ref[s][0])
             assert np.array_equal(got[s][1], ref[s][1])
             assert np.array_equal(got[s][2], ref[s][2].astype(np.uint8))
+
+
+@pytest.mark.parametrize("n_global", [16, 11])
+def test_two_rank_scatter_step_gather_equals_single_process(n_global):
+    """Rank 0 alone holds the action batch: scatter -> step -> gather == the unsharded batch, bit for bit."""
+    ref0, ref = single_process(n_global)
+    (rank, got0, got), = run_world(n_global, "root", inplace=True, scatter=True)
+    assert np.array_equal(got0, ref0)
+    for s in range(4):
+        for j in range(2):
+            assert np.array_equal(got[s][j], ref[s][j])
+
+
+def test_scatter_single_process_passthrough():
+    sc = D.ActionScatter(5, 3, torch.device("cpu"))
+    a = torch.rand(5, 3)
+    assert torch.equal(sc.exchange(a), a) and sc.bytes_per_step() == 5 * 3 * 4
 
 
 def test_gather_single_process_passthrough():
