@@ -70,3 +70,45 @@ def test_episode_accounting_at_full_size():
     ist = h.get_state()[-1].view(np.int32)
     assert np.all(ist == 15 % max_steps)
     h.close()
+
+
+def test_auvenv_half_turn_symmetry_at_full_size():
+    """A symmetry the equations have and no implementation detail should break (the reference probes the observation
+    side of it in tag/script_5_testTransformations.py): without current, turning the whole scene by pi about the target
+    - (x, y, psi, psi_target) -> (-x, -y, psi + pi, psi_target + pi), global force actions (a0, a1, a2) -> (-a0, -a1, a2) -
+    maps a trajectory onto its mirror image: observations 0, 1, 4..7 change sign, 2, 3, 8 and the reward stay.
+    1 048 576 envs x 40 steps; equality up to the fp32 rounding of psi + pi."""
+    n, steps = 1048576, 40
+    rng = np.random.default_rng(12)
+    auv = P.auv_params(noiseMagCoeffs=0.1, noiseMagActuation=0.1, stopOnBoundsExceeded=False)
+    init = np.zeros((n, 16), np.float32)
+    init[:, :2] = (rng.random((n, 2)) - 0.5) * 0.5
+    init[:, 2] = rng.random(n) * np.pi              # psi in [0, pi): psi + pi stays inside [0, 2 pi)
+    init[:, 3] = init[:, 2] + (rng.random(n) - 0.5) * 2.0     # heading error within +-1 rad: away from the +-pi tie
+    init[:, 5:] = 1.0 + 0.05 - rng.random((n, 11)) * 0.1
+    mirror = init.copy()
+    mirror[:, :2] *= -1
+    mirror[:, 2] += np.float32(np.pi)
+    mirror[:, 3] += np.float32(np.pi)
+    sign = np.array([-1, -1, 1, 1, -1, -1, -1, -1, 1, 1, 1], np.float32)
+    ha = _lib.Handle(P.make_config("auv", n, dt=0.02, auto_reset=False, max_steps=10 ** 9, use_flow=False, auv=auv))
+    hb = _lib.Handle(P.make_config("auv", n, dt=0.02, auto_reset=False, max_steps=10 ** 9, use_flow=False, auv=auv))
+    oa, ob = ha.reset(init=init), hb.reset(init=mirror)
+    assert np.max(np.abs(oa - ob * sign)) < 2e-5
+    worst_o = worst_r = 0.0
+    tie = np.zeros(n, bool)     # lanes whose heading error has come within 1e-3 of +-pi: angleError's branch cut
+    for k in range(steps):
+        a = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        b = a * np.array([-1, -1, 1], np.float32)
+        oa, ra, _ = ha.step(a)
+        ob, rb, _ = hb.step(b)
+        herr = ha.get_state()[P.STATE_PLANES[P.MODEL_AUV]["herr_o"]]
+        tie |= np.abs(herr) > np.pi - 1e-3
+        ok = ~tie
+        worst_o = max(worst_o, float(np.max(np.abs(oa[ok] - (ob * sign)[ok]))))
+        worst_r = max(worst_r, float(np.max(np.abs(ra[ok] - rb[ok]) / np.maximum(1.0, np.abs(ra[ok])))))
+    # the heading-error-change observation is scaled by 1/(2 deg): 28.6 x the 4.8e-7 resolution of an angle near 2 pi
+    assert tie.mean() < 1e-3, tie.sum()
+    assert worst_o < 1e-4, worst_o
+    assert worst_r < 1e-4, worst_r
+    ha.close(); hb.close()
