@@ -236,6 +236,18 @@ int mvrl_set_state(mvrl_handle* h, const float* buf, size_t n_elems);
 int mvrl_get_state_f64(mvrl_handle* h, double* buf, size_t n_elems);
 int mvrl_set_state_f64(mvrl_handle* h, const double* buf, size_t n_elems);
 
+/* ---- one evaluation of the vehicle's derivs(t, y) for n independent tuples (unit-level parity, system identification):
+ * BlueROV2Heavy6DoF.derivs 6DoF.py:406-442 (PID :43-73 -> allocateThrust :220 -> thrusterModel/limit -> forceModel
+ * :253-404 -> solve :428 -> J :430) / BlueROV2Heavy3DoF.derivs 3DoF.py:128-296, with the handle's constants.
+ * Row-major host arrays: t[n], y[n,2*dof], sp[n,dof]; controller memory eold[n,dof], eint[n,dof], told[n] is read AND
+ * updated exactly as the call mutates it; has_old[n] = 0 means controller.eOld is None (first call).  Outputs dy[n,2*dof]
+ * and, if non-NULL, the side outputs gcf[n,dof] (controller demand; 3-DoF: resolved into the body frame as the
+ * reference's timeHistory stores it) and rpm[n,8|4].  Zero current.  Rigid-body models only. ---- */
+int mvrl_derivs(mvrl_handle* h, int64_t n, const float* t, const float* y, const float* sp, float* eold, float* eint, float* told,
+                const uint8_t* has_old, float* dy, float* gcf, float* rpm);
+int mvrl_derivs_f64(mvrl_handle* h, int64_t n, const double* t, const double* y, const double* sp, double* eold, double* eint,
+                    double* told, const uint8_t* has_old, double* dy, double* gcf, double* rpm);
+
 /* Per-step side outputs the reference keeps in timeHistory (6DoF.py:578-587: F0..F5, u0..u7; 3DoF: F0..F2,u0..u3;
  * verySimpleAuv.py:389-403: Fx,Fy,N,u_current,v_current,rmsAc,r0..r4).  Enable BEFORE stepping;
  * aux row = [n_envs, aux_dim] f32 with aux_dim = 14 (ROV6) / 7 (ROV3) / 11 (AUV). */

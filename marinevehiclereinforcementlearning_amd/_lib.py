@@ -28,7 +28,7 @@ SYMBOLS = [
     "mvrl_dev_upload", "mvrl_dev_download", "mvrl_synchronize",
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
-    "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev",
+    "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64",
     "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
@@ -99,6 +99,8 @@ def load(path=None):
     lib.mvrl_set_state_f64.argtypes = [vp, vp, C.c_size_t]
     lib.mvrl_get_aux_f64.argtypes = [vp, vp]
     lib.mvrl_get_nfev.argtypes = [vp, vp]
+    lib.mvrl_derivs.argtypes = [vp, i64] + [vp] * 10
+    lib.mvrl_derivs_f64.argtypes = [vp, i64] + [vp] * 10
     lib.mvrl_replay_add_sym_dev.argtypes = [i32] + [vp] * 5 + [i64] + [vp] * 6 + [i64, i64, i32, vp]
     lib.mvrl_policy_create.argtypes = [i32, i32, i64, i32, C.c_double, vp, vp, C.c_double, C.c_double, u64, C.POINTER(vp)]
     lib.mvrl_policy_destroy.argtypes = [vp]
@@ -243,6 +245,26 @@ class Handle:
         """Number of resets each env has gone through = the counter of its Philox stream."""
         st = self.get_state() if state is None else state
         return st[P.STATE_PLANES[self.model]["episode"]].view(self.itype)
+
+    def derivs(self, t, y, sp, eold=None, eint=None, told=None, has_old=None):
+        """vehicle.derivs(t, y) for n tuples (6DoF.py:406-442 / 3DoF.py:128-296).  Returns dict(dy, eold, eint, told, gcf,
+        rpm) - eold/eint/told are the controller memory AFTER the call."""
+        dof = 6 if self.model == P.MODEL_ROV6 else 3
+        nthr = 8 if dof == 6 else 4
+        y = np.ascontiguousarray(np.atleast_2d(y), self.dtype)
+        n = y.shape[0]
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(t, self.dtype), (n,)))
+        sp = np.ascontiguousarray(np.atleast_2d(sp), self.dtype)
+        eo = np.zeros((n, dof), self.dtype) if eold is None else np.array(np.atleast_2d(eold), self.dtype)
+        ei = np.zeros((n, dof), self.dtype) if eint is None else np.array(np.atleast_2d(eint), self.dtype)
+        to = np.zeros(n, self.dtype) if told is None else np.array(np.broadcast_to(np.asarray(told, self.dtype), (n,)))
+        ho = (np.zeros(n, np.uint8) if (has_old is None and eold is None) else
+              np.ones(n, np.uint8) if has_old is None else np.ascontiguousarray(np.broadcast_to(has_old, (n,)), np.uint8))
+        assert y.shape == (n, 2 * dof) and sp.shape == (n, dof) and eo.shape == (n, dof) and ei.shape == (n, dof)
+        dy = np.zeros((n, 2 * dof), self.dtype); gcf = np.zeros((n, dof), self.dtype); rpm = np.zeros((n, nthr), self.dtype)
+        check(self._fn("mvrl_derivs")(self.h, n, t.ctypes.data, y.ctypes.data, sp.ctypes.data, eo.ctypes.data, ei.ctypes.data,
+                                      to.ctypes.data, ho.ctypes.data, dy.ctypes.data, gcf.ctypes.data, rpm.ctypes.data), self.h)
+        return dict(dy=dy, eold=eo, eint=ei, told=to, gcf=gcf, rpm=rpm)
 
     def enable_aux(self, on=True):
         check(self.lib.mvrl_enable_aux(self.h, 1 if on else 0), self.h)

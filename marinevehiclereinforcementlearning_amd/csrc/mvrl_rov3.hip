@@ -132,8 +132,8 @@ __device__ __forceinline__ void random_init3(uint64_t seed, int64_t gid, uint32_
 enum { R3_Y = 0, R3_EOLD = 6, R3_EINT = 9, R3_SP = 12, R3_PATH = 15, R3_EPISODE = 19 /* see mvrl_rov6.hip */, R3_TOLD = 20, R3_TIME = 21,
        R3_TOFF = 22, R3_ISTEP = 23, R3_WORDS = 24 };
 
-#if MVRL_F64
-// BlueROV2Heavy3DoF.derivs (3DoF.py:128-296) with run-time t - tOld, as the RHS functor of the adaptive solver
+// BlueROV2Heavy3DoF.derivs (3DoF.py:128-296) with run-time t - tOld: the RHS functor of the adaptive solver and of
+// rov3_derivs_kernel
 template <bool FLOW, class PP>
 struct Rhs3 {
     PP p;
@@ -172,7 +172,6 @@ struct Rhs3 {
         dynamics3<FLOW>(p, y, c, sn, F, cur, dy);
     }
 };
-#endif
 
 
 template <class PP, bool ZOH, bool FLOW, int INTEG>
@@ -367,6 +366,42 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_reset_kernel(const Rov3Dev* _
 #pragma unroll
         for (int q = 0; q < 5; q++) obs[i * 5 + q] = o[q];
     }
+}
+
+// One evaluation of vehicle.derivs(t, y) for n independent tuples (see rov6_derivs_kernel)
+template <class PP>
+__global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov3_derivs_kernel(const Rov3Dev* __restrict__ pg, int64_t n, const float* t,
+                                                                      const float* y_in, const float* sp_in, float* eold,
+                                                                      float* eint, float* told, const uint8_t* has_old,
+                                                                      float* dy_out, float* aux_out) {
+    const PP p = param_ptr<PP>(pg);
+    const int64_t i = (int64_t)blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float y[6], sp[3], dy[6];
+    Pid3 pid;
+#pragma unroll
+    for (int k = 0; k < 6; k++) y[k] = y_in[i * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { sp[k] = sp_in[i * 3 + k]; pid.eold[k] = eold[i * 3 + k]; pid.eint[k] = eint[i * 3 + k]; }
+    if (!has_old[i]) {  // eOld is None (3DoF.py:144-145)
+        pid.eold[0] = sp[0] - y[0]; pid.eold[1] = sp[1] - y[1]; pid.eold[2] = angle_error(sp[2], y[2]);
+    }
+    float to = told[i];
+    Rhs3<false, PP> rhs{p, sp, &pid, &to, make_float2(0.f, 0.f), aux_out + i * 7};
+    rhs(t[i], y, dy);
+#pragma unroll
+    for (int k = 0; k < 6; k++) dy_out[i * 6 + k] = dy[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { eold[i * 3 + k] = pid.eold[k]; eint[i * 3 + k] = pid.eint[k]; }
+    told[i] = to;
+}
+
+hipError_t launch_rov3_derivs(const Rov3Dev* p, bool baked, int64_t n, const float* t, const float* y, const float* sp, float* eold,
+                              float* eint, float* told, const uint8_t* has_old, float* dy, float* aux, hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
+    if (baked) hipLaunchKernelGGL((rov3_derivs_kernel<const Rov3Baked*>), grid, block, 0, stream, p, n, t, y, sp, eold, eint, told, has_old, dy, aux);
+    else hipLaunchKernelGGL((rov3_derivs_kernel<CP3>), grid, block, 0, stream, p, n, t, y, sp, eold, eint, told, has_old, dy, aux);
+    return hipGetLastError();
 }
 
 hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool zoh, bool flow,

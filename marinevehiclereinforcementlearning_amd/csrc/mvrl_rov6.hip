@@ -329,8 +329,7 @@ __device__ __forceinline__ void random_init6(uint64_t seed, int64_t gid, uint32_
 enum { R6_Y = 0, R6_EOLD = 12, R6_EINT = 18, R6_SP = 24, R6_PATH = 30, R6_EPISODE = 36, R6_TOLD = 37, R6_TIME = 38, R6_TOFF = 39,
        R6_ISTEP = 40, R6_WORDS = 41 };
 
-#if MVRL_F64
-// PID with run-time t - tOld, for the adaptive integrator (6DoF.py:43-73 verbatim)
+// PID with run-time t - tOld (6DoF.py:43-73 verbatim): the adaptive integrator and the stand-alone derivs evaluation
 template <class PP>
 __device__ __forceinline__ void pid6_rt(PP p, const float* y, const float* sp, Pid6& s, float& told, float t, float* u) {
     float e[6];
@@ -351,7 +350,7 @@ __device__ __forceinline__ void pid6_rt(PP p, const float* y, const float* sp, P
     told = t;
 }
 
-// BlueROV2Heavy6DoF.derivs as the RHS functor of the adaptive solver
+// BlueROV2Heavy6DoF.derivs (6DoF.py:406-442) as a functor: the RHS of the adaptive solver, and rov6_derivs_kernel
 template <bool SYM, bool FLOW, class PP>
 struct Rhs6 {
     PP p;
@@ -370,7 +369,6 @@ struct Rhs6 {
         dynamics6<SYM, FLOW>(p, y, tr, ax, F, cur, dy);
     }
 };
-#endif
 
 
 #if defined(MVRL_STAMP) && !MVRL_F64
@@ -639,7 +637,48 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_reset_kernel(const Rov6Dev* _
     }
 }
 
+// One evaluation of vehicle.derivs(t, y) for n independent (state, set-point, controller memory) tuples, row-major
+// [n, dim] arrays - the unit-level entry point (mvrl_derivs): same device functions as the step kernel.
+template <class PP, bool SYM>
+__global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov6_derivs_kernel(const Rov6Dev* __restrict__ pg, int64_t n, const float* t,
+                                                                      const float* y_in, const float* sp_in, float* eold,
+                                                                      float* eint, float* told, const uint8_t* has_old,
+                                                                      float* dy_out, float* aux_out) {
+    const PP p = param_ptr<PP>(pg);
+    const int64_t i = (int64_t)blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float y[12], sp[6], dy[12];
+    Pid6 pid;
+#pragma unroll
+    for (int k = 0; k < 12; k++) y[k] = y_in[i * 12 + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { sp[k] = sp_in[i * 6 + k]; pid.eold[k] = eold[i * 6 + k]; pid.eint[k] = eint[i * 6 + k]; }
+    if (!has_old[i]) {  // controller.eOld is None: the first call differentiates against itself (6DoF.py:62-63)
+#pragma unroll
+        for (int k = 0; k < 5; k++) pid.eold[k] = sp[k] - y[k];
+        pid.eold[5] = angle_error(sp[5], y[5]);
+    }
+    float to = told[i];
+    Rhs6<SYM, false, PP> rhs{p, sp, &pid, &to, make_float2(0.f, 0.f), aux_out + i * 14};
+    rhs(t[i], y, dy);
+#pragma unroll
+    for (int k = 0; k < 12; k++) dy_out[i * 12 + k] = dy[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { eold[i * 6 + k] = pid.eold[k]; eint[i * 6 + k] = pid.eint[k]; }
+    told[i] = to;
+}
+
 // ---- host-side launchers ---------------------------------------------------------------------------
+hipError_t launch_rov6_derivs(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* t, const float* y, const float* sp,
+                              float* eold, float* eint, float* told, const uint8_t* has_old, float* dy, float* aux,
+                              hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
+    if (baked) hipLaunchKernelGGL((rov6_derivs_kernel<const Rov6Baked*, true>), grid, block, 0, stream, p, n, t, y, sp, eold, eint, told, has_old, dy, aux);
+    else if (sym) hipLaunchKernelGGL((rov6_derivs_kernel<CP6, true>), grid, block, 0, stream, p, n, t, y, sp, eold, eint, told, has_old, dy, aux);
+    else hipLaunchKernelGGL((rov6_derivs_kernel<CP6, false>), grid, block, 0, stream, p, n, t, y, sp, eold, eint, told, has_old, dy, aux);
+    return hipGetLastError();
+}
+
 hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool sym, bool zoh,
                             bool flow, bool rk45, hipStream_t stream) {
     dim3 grid((unsigned)((io.n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
