@@ -294,6 +294,14 @@ int mvrl_replay_add_sym_dev(int32_t device, const float* obs, const float* next_
                             int32_t n_transforms, void* stream);
 
 /* ---- benchmark helpers -------------------------------------------------------------------------------- */
+/* Whole episodes of the PD baseline in ONE launch - evaluate_agent(PDController(policy_dt, P, D), AuvEnv)
+ * (tag/resources.py:49-102 driving tag/verySimpleAuv.py:22-50 and :264-410) for every env of the handle: from the env's
+ * current state (call mvrl_reset first) a fresh noise-free PDController acts until `done` or n_steps; the env state
+ * stays in registers between steps.  returns_dev[n] = sum of rewards, lengths_dev[n] = steps taken; the handle is left
+ * in the terminal states (no auto-reset).  fp32 AuvEnv / AuvEnvCyl handles only. */
+int mvrl_auv_pd_episodes_dev(mvrl_handle* h, const double* P, const double* D, double policy_dt, int32_t n_steps, float* returns_dev,
+                             int32_t* lengths_dev, void* stream);
+
 /* Fill a DEVICE buffer with uniform(lo,hi) f32 from the counter-based generator (key seed, stream `counter`). */
 int mvrl_fill_uniform_dev(mvrl_handle* h, float* dst_dev, int64_t n, uint64_t seed, uint64_t counter, float lo,
                           float hi, void* stream);

@@ -29,7 +29,7 @@ SYMBOLS = [
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
     "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64",
-    "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
+    "mvrl_auv_pd_episodes_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
 
@@ -101,6 +101,7 @@ def load(path=None):
     lib.mvrl_get_nfev.argtypes = [vp, vp]
     lib.mvrl_derivs.argtypes = [vp, i64] + [vp] * 10
     lib.mvrl_derivs_f64.argtypes = [vp, i64] + [vp] * 10
+    lib.mvrl_auv_pd_episodes_dev.argtypes = [vp, vp, vp, C.c_double, i32, vp, vp, vp]
     lib.mvrl_replay_add_sym_dev.argtypes = [i32] + [vp] * 5 + [i64] + [vp] * 6 + [i64, i64, i32, vp]
     lib.mvrl_policy_create.argtypes = [i32, i32, i64, i32, C.c_double, vp, vp, C.c_double, C.c_double, u64, C.POINTER(vp)]
     lib.mvrl_policy_destroy.argtypes = [vp]
@@ -291,6 +292,12 @@ class Handle:
 
     def fill_uniform_dev(self, ptr, n, seed, counter, lo=-1.0, hi=1.0, stream=None):
         check(self.lib.mvrl_fill_uniform_dev(self.h, ptr, n, seed, counter, lo, hi, stream), self.h)
+
+    def auv_pd_episodes_dev(self, P_gain, D_gain, policy_dt, n_steps, returns_ptr, lengths_ptr, stream=None):
+        Pa = (C.c_double * 3)(*[float(v) for v in P_gain])
+        Da = (C.c_double * 3)(*[float(v) for v in D_gain])
+        check(self.lib.mvrl_auv_pd_episodes_dev(self.h, Pa, Da, float(policy_dt), int(n_steps), returns_ptr, lengths_ptr, stream),
+              self.h)
 
     def count_launches(self, k):
         """Step launches replayed from a captured graph do not pass through the library: account for them here so

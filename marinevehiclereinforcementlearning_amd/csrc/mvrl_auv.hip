@@ -71,6 +71,111 @@ __device__ __forceinline__ void random_init_auv(const AuvDev& p, uint64_t seed, 
     v[4] = u[15] * t_quarter;
 }
 
+// Everything one AuvEnv lane carries between steps, in registers
+struct AuvLane {
+    float x, y, psi, vx, vy, r;
+    float tgt, tx, ty;              // headingTarget, positionTarget (0 for AuvEnv, waypoints[iWp] for AuvEnvCyl)
+    float herr_o, perr_ox, perr_oy;
+    float mu[11];
+    float hist[30];
+    float toff;
+    int istep, iwp;
+};
+struct AuvStepOut {
+    float o[11];
+    float reward;
+    bool done, time_up;
+    int slot;
+    float Fg0, Fg1, Fh2, curx, cury, rms, t0, t1, t2, t3, bonus;   // timeHistory side outputs (:389-403)
+};
+
+// AuvEnv.step (verySimpleAuv.py:264-410) / AuvEnvCyl.step for one lane: shared by the step kernel and the fused
+// PD-episode kernel, so both run the same arithmetic.
+template <bool FLOW>
+__device__ __forceinline__ void auv_step_core(const AuvDev& p, const FlowDev& fl, AuvLane& s, float a0, float a1, float a2,
+                                              float dt, int max_steps, AuvStepOut& out) {
+    const bool cyl = p.n_wp > 0;
+    s.istep += 1;                                  // verySimpleAuv.py:266
+    const float time = (float)s.istep * dt;        // :267
+    const bool time_up = s.istep >= max_steps;     // :270-272
+    bool done = time_up;
+    const int slot = (s.istep - 1) % 10;           // recentActions.appendleft (:275) as a ring
+    const int nh = s.istep < 10 ? s.istep : 10;
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        s.hist[3 * j + 0] = (j == slot) ? a0 : s.hist[3 * j + 0];
+        s.hist[3 * j + 1] = (j == slot) ? a1 : s.hist[3 * j + 1];
+        s.hist[3 * j + 2] = (j == slot) ? a2 : s.hist[3 * j + 2];
+    }
+    const float Fset0 = a0 * p.max_force * s.mu[8], Fset1 = a1 * p.max_force * s.mu[9];   // :278
+    const float Nset = a2 * p.max_moment * s.mu[10];                                        // :279
+    float sn, c;
+    sincos_f32(s.psi, sn, c);
+    float2 cur = make_float2(0.f, 0.f);
+    if (FLOW) cur = flow_interp_uv(fl, time + s.toff, s.x, s.y);                            // :291
+    const float dvx = s.vx - cur.x, dvy = s.vy - cur.y;
+    const float vr0 = c * dvx + sn * dvy, vr1 = -sn * dvx + c * dvy;                        // :298 (pinv(J) = J^T)
+    const float Fh0 = (p.xu * s.mu[5] + p.xuu * s.mu[2] * fabsf(vr0)) * vr0;                // :303-307
+    const float Fh1 = (p.yv * s.mu[6] + p.yvv * s.mu[3] * fabsf(vr1)) * vr1;
+    const float Fh2 = (p.nr * s.mu[7] + p.nrr * s.mu[4] * fabsf(s.r)) * s.r;
+    const float Fg0 = c * Fh0 - sn * Fh1, Fg1 = sn * Fh0 + c * Fh1;                         // :310
+    const float acc0 = (Fg0 + Fset0) / (p.m * s.mu[0]);                                     // :314-318
+    const float acc1 = (Fg1 + Fset1) / (p.m * s.mu[0]);
+    const float acc2 = (Fh2 + Nset) / (p.izz * s.mu[1]);
+    const float h = dt;                                                                     // :321-326 explicit Euler
+    s.x = fmaf(s.vx, h, s.x); s.y = fmaf(s.vy, h, s.y);
+    s.psi = mod_two_pi(fmaf(s.r, h, s.psi));
+    s.vx = fmaf(acc0, h, s.vx); s.vy = fmaf(acc1, h, s.vy); s.r = fmaf(acc2, h, s.r);
+
+    observe_auv(p, s.x, s.y, s.psi, s.vx, s.vy, s.r, s.tx, s.ty, s.tgt, s.herr_o, s.perr_ox, s.perr_oy, out.o);    // :329
+    float bonus = 0.f;                                                                      // :335-342
+    if (s.x < p.x_min || s.x > p.x_max) { if (p.stop_on_bounds) done = true; bonus += -100.f; }
+    if (s.y < p.y_min || s.y > p.y_max) { if (p.stop_on_bounds) done = true; bonus += -100.f; }
+    const float perr0 = s.tx - s.x, perr1 = s.ty - s.y;
+    const float herr = angle_error(s.tgt, s.psi);
+    if (cyl && sqrtf(perr0 * perr0 + perr1 * perr1) < p.wp_thr) {                           // _cyl.py:249-253
+        s.iwp = min(p.n_wp - 1, s.iwp + 1);
+        waypoint(p, s.iwp, s.tx, s.ty, s.tgt);
+    }
+    s.herr_o = herr; s.perr_ox = perr0; s.perr_oy = perr1;                                  // :349-350
+    float rms = 0.f;                                                                        // :353-355
+    const float inv_nh = 1.0f / (float)nh;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float mean = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; j++) mean += (j < nh) ? s.hist[3 * j + k] : 0.f;
+        mean *= inv_nh;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; j++) { float d = s.hist[3 * j + k] - mean; ss += (j < nh) ? d * d : 0.f; }
+        rms += sqrtf(ss * inv_nh);
+    }
+    rms *= (1.0f / 3.0f);
+    const float PI = 3.14159265358979323846f;
+    const float hdeg = herr * (180.0f / PI);
+    const float t0 = expf(-5.f * sqrtf(perr0 * perr0 + perr1 * perr1));                     // :357-381
+    const float t1 = (fabsf(herr) < 0.5f * PI) ? expf(-0.1f * fabsf(hdeg)) : -expf(-0.1f * (180.f - fabsf(hdeg)));
+    const float t2 = expf(-0.6f * rms);
+    const float t3 = -0.1f * (a0 * a0 + a1 * a1 + a2 * a2) * (1.0f / 3.0f);
+    out.reward = (((t0 + t1) + t2) + t3) + bonus;
+    out.done = done; out.time_up = time_up; out.slot = slot;
+    out.Fg0 = Fg0; out.Fg1 = Fg1; out.Fh2 = Fh2; out.curx = cur.x; out.cury = cur.y; out.rms = rms;
+    out.t0 = t0; out.t1 = t1; out.t2 = t2; out.t3 = t3; out.bonus = bonus;
+}
+
+#define MVRL_AUV_LOAD_LANE(s)                                                                                         \
+    do {                                                                                                              \
+        (s).x = ST(AV_X); (s).y = ST(AV_Y); (s).psi = ST(AV_PSI); (s).vx = ST(AV_VX); (s).vy = ST(AV_VY); (s).r = ST(AV_R); \
+        (s).tgt = ST(AV_TGT); (s).tx = 0.f; (s).ty = 0.f; (s).iwp = 0;  /* positionTarget = 0 for AuvEnv (:241) */        \
+        if (p.n_wp > 0) { (s).iwp = unpack_int(ST(AV_IWP)); waypoint(p, (s).iwp, (s).tx, (s).ty, (s).tgt); }              \
+        (s).herr_o = ST(AV_HERR_O); (s).perr_ox = ST(AV_PERR_O); (s).perr_oy = ST(AV_PERR_O + 1);                       \
+        _Pragma("unroll") for (int q_ = 0; q_ < 11; q_++) (s).mu[q_] = ST(AV_MULT + q_);                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < 30; q_++) (s).hist[q_] = ST(AV_HIST + q_);                             \
+        (s).istep = unpack_int(ST(AV_ISTEP));                                                                         \
+        (s).toff = FLOW ? ST(AV_TOFF) : 0.f;                                                                          \
+    } while (0)
+
 template <bool FLOW>
 __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, const StepIO io, const FlowDev fl) {
     const uint32_t i = blockIdx.x * MVRL_BLOCK + threadIdx.x;
@@ -78,92 +183,28 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     const uint32_t n32 = (uint32_t)io.n;
     char* const stb = reinterpret_cast<char*>(io.state);
 #define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) * (uint32_t)sizeof(float))))
-    float x = ST(AV_X), y = ST(AV_Y), psi = ST(AV_PSI), vx = ST(AV_VX), vy = ST(AV_VY), r = ST(AV_R);
-    float tgt = ST(AV_TGT), tx = 0.f, ty = 0.f;   // positionTarget = 0 for AuvEnv (verySimpleAuv.py:241)
-    int iwp = 0;
     const bool cyl = p.n_wp > 0;
-    if (cyl) { iwp = unpack_int(ST(AV_IWP)); waypoint(p, iwp, tx, ty, tgt); }
-    float herr_o = ST(AV_HERR_O), perr_ox = ST(AV_PERR_O), perr_oy = ST(AV_PERR_O + 1);
-    float mu[11];
-#pragma unroll
-    for (int q = 0; q < 11; q++) mu[q] = ST(AV_MULT + q);
-    float hist[30];
-#pragma unroll
-    for (int q = 0; q < 30; q++) hist[q] = ST(AV_HIST + q);
-    int istep = unpack_int(ST(AV_ISTEP));
+    AuvLane s;
+    MVRL_AUV_LOAD_LANE(s);
     const float* ap = io.actions + (size_t)i * 3;
     const float a0 = ap[0], a1 = ap[1], a2 = ap[2];
-
-    istep += 1;                                  // verySimpleAuv.py:266
-    const float time = (float)istep * io.dt;     // :267
-    const bool time_up = istep >= io.max_steps;  // :270-272
-    bool done = time_up;
-    const int slot = (istep - 1) % 10;           // recentActions.appendleft (:275) as a ring
-    const int nh = istep < 10 ? istep : 10;
-#pragma unroll
-    for (int j = 0; j < 10; j++) {
-        hist[3 * j + 0] = (j == slot) ? a0 : hist[3 * j + 0];
-        hist[3 * j + 1] = (j == slot) ? a1 : hist[3 * j + 1];
-        hist[3 * j + 2] = (j == slot) ? a2 : hist[3 * j + 2];
-    }
-    const float Fset0 = a0 * p.max_force * mu[8], Fset1 = a1 * p.max_force * mu[9];   // :278
-    const float Nset = a2 * p.max_moment * mu[10];                                      // :279
-    float sn, c;
-    sincos_f32(psi, sn, c);
-    float2 cur = make_float2(0.f, 0.f);
-    if (FLOW) cur = flow_interp_uv(fl, time + ST(AV_TOFF), x, y);                       // :291
-    const float dvx = vx - cur.x, dvy = vy - cur.y;
-    const float vr0 = c * dvx + sn * dvy, vr1 = -sn * dvx + c * dvy;                    // :298 (pinv(J) = J^T)
-    const float Fh0 = (p.xu * mu[5] + p.xuu * mu[2] * fabsf(vr0)) * vr0;                // :303-307
-    const float Fh1 = (p.yv * mu[6] + p.yvv * mu[3] * fabsf(vr1)) * vr1;
-    const float Fh2 = (p.nr * mu[7] + p.nrr * mu[4] * fabsf(r)) * r;
-    const float Fg0 = c * Fh0 - sn * Fh1, Fg1 = sn * Fh0 + c * Fh1;                     // :310
-    const float acc0 = (Fg0 + Fset0) / (p.m * mu[0]);                                   // :314-318
-    const float acc1 = (Fg1 + Fset1) / (p.m * mu[0]);
-    const float acc2 = (Fh2 + Nset) / (p.izz * mu[1]);
-    const float h = io.dt;                                                              // :321-326 explicit Euler
-    x = fmaf(vx, h, x); y = fmaf(vy, h, y);
-    psi = mod_two_pi(fmaf(r, h, psi));
-    vx = fmaf(acc0, h, vx); vy = fmaf(acc1, h, vy); r = fmaf(acc2, h, r);
-
+    AuvStepOut out;
+    auv_step_core<FLOW>(p, fl, s, a0, a1, a2, io.dt, io.max_steps, out);
+    // the kernel body below keeps its historical local names
+    float x = s.x, y = s.y, psi = s.psi, vx = s.vx, vy = s.vy, r = s.r, tgt = s.tgt, tx = s.tx, ty = s.ty;
+    float herr_o = s.herr_o, perr_ox = s.perr_ox, perr_oy = s.perr_oy;
+    int istep = s.istep, iwp = s.iwp;
+    const bool done = out.done, time_up = out.time_up;
+    const int slot = out.slot;
     float o[11];
-    observe_auv(p, x, y, psi, vx, vy, r, tx, ty, tgt, herr_o, perr_ox, perr_oy, o);    // :329
-    float bonus = 0.f;                                                                  // :335-342
-    if (x < p.x_min || x > p.x_max) { if (p.stop_on_bounds) done = true; bonus += -100.f; }
-    if (y < p.y_min || y > p.y_max) { if (p.stop_on_bounds) done = true; bonus += -100.f; }
-    const float perr0 = tx - x, perr1 = ty - y;
-    const float herr = angle_error(tgt, psi);
-    if (cyl && sqrtf(perr0 * perr0 + perr1 * perr1) < p.wp_thr) {                       // _cyl.py:249-253
-        iwp = min(p.n_wp - 1, iwp + 1);
-        waypoint(p, iwp, tx, ty, tgt);
-    }
-    herr_o = herr; perr_ox = perr0; perr_oy = perr1;                                    // :349-350
-    float rms = 0.f;                                                                    // :353-355
-    const float inv_nh = 1.0f / (float)nh;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        float mean = 0.f;
-#pragma unroll
-        for (int j = 0; j < 10; j++) mean += (j < nh) ? hist[3 * j + k] : 0.f;
-        mean *= inv_nh;
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 10; j++) { float d = hist[3 * j + k] - mean; ss += (j < nh) ? d * d : 0.f; }
-        rms += sqrtf(ss * inv_nh);
-    }
-    rms *= (1.0f / 3.0f);
-    const float PI = 3.14159265358979323846f;
-    const float hdeg = herr * (180.0f / PI);
-    const float t0 = expf(-5.f * sqrtf(perr0 * perr0 + perr1 * perr1));                 // :357-381
-    const float t1 = (fabsf(herr) < 0.5f * PI) ? expf(-0.1f * fabsf(hdeg)) : -expf(-0.1f * (180.f - fabsf(hdeg)));
-    const float t2 = expf(-0.6f * rms);
-    const float t3 = -0.1f * (a0 * a0 + a1 * a1 + a2 * a2) * (1.0f / 3.0f);
-    io.reward[i] = (((t0 + t1) + t2) + t3) + bonus;
+    for (int q = 0; q < 11; q++) o[q] = out.o[q];
+    io.reward[i] = out.reward;
     io.done[i] = done ? (time_up ? 3 : 1) : 0;  // bit 0 = done, bit 1 = time limit (else: bounds exceeded)
     if (io.aux) {  // timeHistory: Fx Fy N u_current v_current rmsAc r0..r4 (:389-403)
         float* ax = io.aux + (size_t)i * 11;
-        ax[0] = Fg0; ax[1] = Fg1; ax[2] = Fh2; ax[3] = cur.x; ax[4] = cur.y; ax[5] = rms;
-        ax[6] = t0; ax[7] = t1; ax[8] = t2; ax[9] = t3; ax[10] = bonus;
+        ax[0] = out.Fg0; ax[1] = out.Fg1; ax[2] = out.Fh2; ax[3] = out.curx; ax[4] = out.cury; ax[5] = out.rms;
+        ax[6] = out.t0; ax[7] = out.t1; ax[8] = out.t2; ax[9] = out.t3; ax[10] = out.bonus;
     }
     if (done && io.auto_reset) {
         if (io.term_obs) {
@@ -218,6 +259,74 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     if (cyl) ST(AV_IWP) = pack_int(iwp);
     ST(AV_ISTEP) = pack_int(istep);
 #undef ST
+}
+
+// Whole episodes of the PD baseline in one launch: evaluate_agent(PDController, AuvEnv) (tag/resources.py:49-102 driving
+// verySimpleAuv.py:22-50 and :264-410) for every env of the batch, from its current state until `done` or n_steps.
+// The lane's state never leaves its registers between steps: no state round trip through HBM, no observation or
+// action arrays, no launch per step - per env the kernel reads 55 words once, gathers the current at every step and
+// writes a return, a length and the terminal state.  Same device functions as the step-by-step path
+// (pd_policy_kernel + auv_step_kernel), so the two agree to fp32 rounding of the return sum.
+template <bool FLOW>
+__global__ __launch_bounds__(MVRL_BLOCK) void auv_pd_episode_kernel(const AuvDev p, const FlowDev fl, float* __restrict__ state,
+                                                                    int64_t n, float dt, int max_steps, int n_steps,
+                                                                    float inv_pdt, float p0, float p1, float p2, float d0,
+                                                                    float d1, float d2, float* __restrict__ returns,
+                                                                    int32_t* __restrict__ lengths) {
+    const uint32_t i = blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= (uint32_t)n) return;
+    const uint32_t n32 = (uint32_t)n;
+    char* const stb = reinterpret_cast<char*>(state);
+#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) * (uint32_t)sizeof(float))))
+    AuvLane s;
+    MVRL_AUV_LOAD_LANE(s);
+    const float P[3] = {p0, p1, p2}, D[3] = {d0, d1, d2};
+    float o[11], old[3];
+    observe_auv(p, s.x, s.y, s.psi, s.vx, s.vy, s.r, s.tx, s.ty, s.tgt, s.herr_o, s.perr_ox, s.perr_oy, o);
+#pragma unroll
+    for (int k = 0; k < 3; k++) old[k] = o[k];     // PDController.oldObs is None on the first call
+    float ret = 0.f;
+    int len = 0;
+    bool alive = true;
+    for (int t = 0; t < n_steps; t++) {
+        if (!alive) continue;                       // lanes that hit the bounds early idle until the wave is done
+        float a[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {               // PDController.predict (verySimpleAuv.py:32-50), noise-free
+            const float xk = o[k];
+            float ak = clampf(xk * P[k] + (xk - old[k]) * inv_pdt * D[k], -1.f, 1.f);
+            a[k] = clampf(ak + 0.f, -1.f, 1.f);
+            old[k] = xk;
+        }
+        AuvStepOut out;
+        auv_step_core<FLOW>(p, fl, s, a[0], a[1], a[2], dt, max_steps, out);
+        ret += out.reward;
+        len += 1;
+#pragma unroll
+        for (int q = 0; q < 11; q++) o[q] = out.o[q];
+        alive = !out.done;
+    }
+    returns[i] = ret;
+    lengths[i] = len;
+    ST(AV_X) = s.x; ST(AV_Y) = s.y; ST(AV_PSI) = s.psi; ST(AV_VX) = s.vx; ST(AV_VY) = s.vy; ST(AV_R) = s.r;
+    ST(AV_HERR_O) = s.herr_o; ST(AV_PERR_O) = s.perr_ox; ST(AV_PERR_O + 1) = s.perr_oy;
+    ST(AV_TGT) = s.tgt;
+    if (p.n_wp > 0) ST(AV_IWP) = pack_int(s.iwp);
+#pragma unroll
+    for (int q = 0; q < 30; q++) ST(AV_HIST + q) = s.hist[q];
+    ST(AV_ISTEP) = pack_int(s.istep);
+#undef ST
+}
+
+hipError_t launch_auv_pd_episodes(const AuvDev& p, const FlowDev& fl, bool flow, float* state, int64_t n, float dt, int max_steps,
+                                  int n_steps, float policy_dt, const float* P, const float* D, float* returns, int32_t* lengths,
+                                  hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    if (flow) hipLaunchKernelGGL((auv_pd_episode_kernel<true>), grid, block, 0, stream, p, fl, state, n, dt, max_steps, n_steps,
+                                 1.0f / policy_dt, P[0], P[1], P[2], D[0], D[1], D[2], returns, lengths);
+    else hipLaunchKernelGGL((auv_pd_episode_kernel<false>), grid, block, 0, stream, p, fl, state, n, dt, max_steps, n_steps,
+                            1.0f / policy_dt, P[0], P[1], P[2], D[0], D[1], D[2], returns, lengths);
+    return hipGetLastError();
 }
 
 __global__ __launch_bounds__(MVRL_BLOCK) void auv_reset_kernel(const AuvDev p, float* state, int64_t n, const uint8_t* mask,

@@ -74,6 +74,23 @@ class PDController(_DevicePolicy):
                          device=device)
 
 
+    def run_episodes(self, venv, n_steps=None):
+        """One whole episode of this (noise-free) controller in every env of `venv` (a MarineVecEnv("auv" | "auv_cyl")), fused
+        into one kernel launch: the device-side counterpart of resources.evaluate_agent(PDController, env)
+        (tag/resources.py:49-102).  Starts from the envs' current states (call venv.reset() / reset_tensors() first), stops
+        each env at `done` or after n_steps (default: the env's episode length).  Returns (returns, lengths) torch tensors."""
+        import torch
+        if self.noiseSigma:
+            raise ValueError("run_episodes evaluates the deterministic controller (noiseSigma=None)")
+        n = venv.num_envs
+        dev = torch.device("cuda", venv.cfg.device)
+        ret = torch.empty((n,), dtype=torch.float32, device=dev)
+        length = torch.empty((n,), dtype=torch.int32, device=dev)
+        venv.handle.auv_pd_episodes_dev(self.P, self.D, self.dt, int(n_steps or venv.cfg.max_steps), ret.data_ptr(),
+                                        length.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return ret, length
+
+
 class LOSNavigation(_DevicePolicy):
     """LOSNavigation() of the reference (Rnav = 0.5, observations of the 3-DoF env)."""
 
