@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
+    ap.add_argument("--rollout", action="store_true", help="step through mvrl_rollout_dev: the RING action batches per call "
+                    "(one fused launch of 8 env steps for the 6-DoF kernels) - open-loop roll-outs, not the per-step VecEnv path")
     ap.add_argument("--graph", action="store_true", help="replay the RING step launches from a captured HIP graph "
                     "(pays off when the batch is small enough to be launch-bound: DESIGN.md section 5)")
     ap.add_argument("--gather", default="root", choices=["root", "all", "none"])
@@ -196,6 +198,10 @@ def main():
                 buf.add(st[0], nobs, act, rew, done)
                 st[0].copy_(nobs)
             return
+        if roll_out is not None and steps % RING == 0:
+            for _ in range(steps // RING):
+                env.rollout_tensors(ring, out=roll_out)
+            return
         if graph is not None and steps % RING == 0:
             for _ in range(steps // RING):
                 graph.replay()
@@ -204,6 +210,11 @@ def main():
         for k in range(steps):
             env.step_tensors(ring[k % RING])
 
+    roll_out = None
+    if args.rollout and loop_objs is None and pd_obj is None:
+        rt = ring.dtype
+        roll_out = (torch.empty((RING, n, obs_dim), dtype=rt, device=dev), torch.empty((RING, n), dtype=rt, device=dev),
+                    torch.empty((RING, n), dtype=torch.uint8, device=dev))
     graph = None
     if args.graph and loop_objs is None:
         # one HIP graph of RING consecutive step launches (the env's RNG position lives in its state, so a replay is
@@ -285,6 +296,7 @@ def main():
                                    "PDController kernel on the previous observation" if loop_objs is not None else
                                    f"ring of {RING} pre-generated uniform(-1,1) batches in HBM"),
                        "launch": ("one launch per 250-step episode batch" if pd_obj is not None else
+                                  "mvrl_rollout_dev: %d env steps per call" % RING if roll_out is not None else
                                   "hip graph of %d steps" % RING if graph is not None else "one launch per step"),
                        "collective_in_value": "none: shards are independent, outputs stay in each rank's HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

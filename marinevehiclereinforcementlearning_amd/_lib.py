@@ -29,7 +29,7 @@ SYMBOLS = [
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
     "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64",
-    "mvrl_auv_pd_episodes_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
+    "mvrl_auv_pd_episodes_dev", "mvrl_rollout_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
 
@@ -101,6 +101,7 @@ def load(path=None):
     lib.mvrl_get_nfev.argtypes = [vp, vp]
     lib.mvrl_derivs.argtypes = [vp, i64] + [vp] * 10
     lib.mvrl_derivs_f64.argtypes = [vp, i64] + [vp] * 10
+    lib.mvrl_rollout_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.mvrl_auv_pd_episodes_dev.argtypes = [vp, vp, vp, C.c_double, i32, vp, vp, vp]
     lib.mvrl_replay_add_sym_dev.argtypes = [i32] + [vp] * 5 + [i64] + [vp] * 6 + [i64, i64, i32, vp]
     lib.mvrl_policy_create.argtypes = [i32, i32, i64, i32, C.c_double, vp, vp, C.c_double, C.c_double, u64, C.POINTER(vp)]
@@ -283,6 +284,9 @@ class Handle:
     # -- device-pointer API (ints = raw device addresses, e.g. torch.Tensor.data_ptr()) -------------
     def step_dev(self, actions_ptr, obs_ptr, reward_ptr, done_ptr, stream=None):
         check(self.lib.mvrl_step_dev(self.h, actions_ptr, obs_ptr, reward_ptr, done_ptr, stream), self.h)
+
+    def rollout_dev(self, actions_ptr, obs_ptr, reward_ptr, done_ptr, k_steps, stream=None):
+        check(self.lib.mvrl_rollout_dev(self.h, actions_ptr, obs_ptr, reward_ptr, done_ptr, int(k_steps), stream), self.h)
 
     def reset_dev(self, mask_ptr, init_ptr, obs_ptr, stream=None):
         check(self.lib.mvrl_reset_dev(self.h, mask_ptr, init_ptr, obs_ptr, stream), self.h)

@@ -293,6 +293,7 @@ struct StepIO {
     int fixed_sp;
     int auto_reset;
     float dt;
+    int k_steps;            // > 1: fused multi-step launch (actions / obs / reward / done are [k_steps][n][...])
 };
 
 }  // namespace mvrl

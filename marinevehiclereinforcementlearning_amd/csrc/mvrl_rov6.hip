@@ -385,11 +385,24 @@ __device__ unsigned long long g_stamp[5 * MVRL_STAMP_WAVES];
 #define STAMP(slot) do {} while (0)
 #endif
 
-template <class PP, bool SYM, bool ZOH, bool FLOW, int INTEG>
+// MULTI: io.k_steps consecutive env steps in ONE launch (mvrl_rollout_dev): the same body run k_steps times on
+// actions[k] -> obs[k] / reward[k] / done[k], k = 0 .. k_steps-1.  A lane only ever touches its own planes, so no
+// synchronisation is needed between the steps; what the fused launch saves is the ~6 us between dependent launches, the
+// ramp and tail of every launch, and the HBM latency of the state loads (the lane's planes come back from L2).
+template <class PP, bool SYM, bool ZOH, bool FLOW, int INTEG, bool MULTI = false>
 __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
     const uint32_t i_in = blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
     if (i_in >= (uint32_t)io.n) return;
+    const int k_steps = MULTI ? io.k_steps : 1;
+#pragma nounroll
+    for (int kstep = 0; kstep < k_steps; kstep++) {
+    const float* const actions_k = (MULTI && io.actions) ? io.actions + (size_t)kstep * (size_t)io.n * 6 : io.actions;
+    float* const obs_k = MULTI ? io.obs + (size_t)kstep * (size_t)io.n * 9 : io.obs;
+    float* const reward_k = MULTI ? io.reward + (size_t)kstep * (size_t)io.n : io.reward;
+    uint8_t* const done_k = MULTI ? io.done + (size_t)kstep * (size_t)io.n : io.done;
+    uint32_t i_k = i_in;
+    if (MULTI) asm volatile("" : "+v"(i_k));  // plane addresses are recomputed per step instead of living across the loop
     STAMP(0);
     // plane k of env i = state[k * n + i] with a 32-bit element index: the access lowers to the
     // `global_load_dword v, v_off, s[base:base+1]` form (uniform 64-bit base in SGPRs + one 32-bit VGPR offset)
@@ -397,7 +410,7 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
     const uint32_t n32 = (uint32_t)io.n;
     char* const stb = reinterpret_cast<char*>(io.state);
 #define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) * (uint32_t)sizeof(float))))
-#define LANE i_in
+#define LANE i_k
 
     float y[12], sp[6], path[6];
     Pid6 pid;
@@ -418,7 +431,7 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
     // on the bulk of the state): fixed set-point -> the stored planes (6DoF.py:536-541), else the action row
     float spin[6];
     {
-        const float* arow = io.fixed_sp ? nullptr : io.actions + (size_t)i_in * 6;
+        const float* arow = io.fixed_sp ? nullptr : actions_k + (size_t)i_in * 6;
 #pragma unroll
         for (int k = 0; k < 6; k++) spin[k] = io.fixed_sp ? ST(R6_SP + k) : arow[k];
     }
@@ -541,8 +554,8 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
     observe6(p, y, path, sp, o);
     const bool done = istep >= io.max_steps;  // 6DoF.py:569-571
 
-    io.reward[i] = 0.f;  // 6DoF.py:575
-    io.done[i] = done ? 3 : 0;  // bit 0 = done, bit 1 = time limit (TimeLimit.truncated)
+    reward_k[i] = 0.f;  // 6DoF.py:575
+    done_k[i] = done ? 3 : 0;  // bit 0 = done, bit 1 = time limit (TimeLimit.truncated)
 
     if (done && io.auto_reset) {
         // SB3 VecEnv semantics: keep the terminal observation, hand back the first observation of a new episode
@@ -573,7 +586,7 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
         observe6(p, y, path, sp, o);
     }
 #pragma unroll
-    for (int q = 0; q < 9; q++) io.obs[(size_t)i * 9 + q] = o[q];
+    for (int q = 0; q < 9; q++) obs_k[(size_t)i * 9 + q] = o[q];
 #pragma unroll
     for (int k = 0; k < 12; k++) ST(R6_Y + k) = y[k];
 #pragma unroll
@@ -588,6 +601,7 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
     asm volatile("s_waitcnt vmcnt(0)");
     STAMP(4);
 #endif
+    }  // kstep
 }
 
 #ifdef MVRL_STAMP_ON
@@ -693,6 +707,18 @@ hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& f
         return hipGetLastError();
     }
 #endif
+    if (io.k_steps > 1) {  // fused multi-step launch: instantiated for the baked and sym flavours (the caller loops otherwise)
+#define MVRL_L6M(PPT, Z, F) hipLaunchKernelGGL((rov6_step_kernel<PPT, true, Z, F, 0, true>), grid, block, 0, stream, p, io, fl)
+        if (baked) {
+            if (zoh) { if (flow) MVRL_L6M(const Rov6Baked*, true, true); else MVRL_L6M(const Rov6Baked*, true, false); }
+            else { if (flow) MVRL_L6M(const Rov6Baked*, false, true); else MVRL_L6M(const Rov6Baked*, false, false); }
+        } else {
+            if (zoh) { if (flow) MVRL_L6M(CP6, true, true); else MVRL_L6M(CP6, true, false); }
+            else { if (flow) MVRL_L6M(CP6, false, true); else MVRL_L6M(CP6, false, false); }
+        }
+#undef MVRL_L6M
+        return hipGetLastError();
+    }
     if (baked) {
         if (zoh) { if (flow) MVRL_L6B(true, true); else MVRL_L6B(true, false); }
         else { if (flow) MVRL_L6B(false, true); else MVRL_L6B(false, false); }

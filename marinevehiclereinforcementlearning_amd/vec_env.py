@@ -198,6 +198,25 @@ class MarineVecEnv:
 
     supports_out = True
 
+    def rollout_tensors(self, actions, out=None):
+        """K consecutive env steps on device: `actions` [K, N, act_dim] (contiguous) -> (obs [K, N, obs_dim], reward [K, N],
+        done_bits [K, N]) - the results of K step_tensors calls (auto-resets included), in one launch for the fp32 6-DoF
+        kernels (mvrl_rollout_dev).  For open-loop roll-outs: recorded / random / repeated actions."""
+        import torch
+        rt = torch.float64 if self._h.f64 else torch.float32
+        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == rt and actions.dim() == 3
+        k, n, od = actions.shape[0], self.num_envs, self.observation_space.shape[0]
+        assert tuple(actions.shape[1:]) == (n, self.action_space.shape[0])
+        if out is None:
+            out = (torch.empty((k, n, od), dtype=rt, device=actions.device), torch.empty((k, n), dtype=rt, device=actions.device),
+                   torch.empty((k, n), dtype=torch.uint8, device=actions.device))
+        obs, rew, done = out
+        assert obs.is_contiguous() and rew.is_contiguous() and done.is_contiguous()
+        assert tuple(obs.shape) == (k, n, od) and tuple(rew.shape) == (k, n) and tuple(done.shape) == (k, n)
+        self._h.rollout_dev(actions.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), k,
+                            torch.cuda.current_stream().cuda_stream)
+        return obs, rew, done
+
     def step_tensors(self, actions, out=None):
         """Device-resident step: `actions` is a contiguous float32 CUDA(HIP) tensor [N, act_dim]; returns
         (obs, reward, done_bits) tensors that are overwritten by the next call.  Enqueued on torch's current stream;

@@ -517,3 +517,34 @@ def test_fused_pd_episodes_equal_step_by_step(kind, n_steps):
     with pytest.raises(ValueError):
         PDController(0.02, noiseSigma=0.1, num_envs=n, device=0).run_episodes(b)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("kind,kw", [("rov6", dict()), ("rov6", dict(control_mode="zoh")), ("rov6", dict(flavour="sym")),
+                                     ("rov6", dict(flavour="generic")), ("rov3", dict()), ("auv", dict())])
+def test_rollout_equals_k_steps(kind, kw):
+    """mvrl_rollout_dev / MarineVecEnv.rollout_tensors: K env steps per call == K step_tensors calls, bit for bit, random
+    auto-resets included - fused into one launch for the fp32 6-DoF baked / sym kernels, launch by launch otherwise."""
+    n, K, reps = 3000, 6, 4
+    flow = ReconstructedFlow.synthetic(n_modes=4, n_time=128, device=0)
+    flow.scale(11., 1., 2., translate=(-1.65, -1.1))
+    kw = dict(kw)
+    flavour = kw.pop("flavour", None)
+    extra = {}
+    if flavour == "sym":
+        extra["vehicle_params"] = P.rov6_params(m=12.0, Xuu=-19.0)
+    if flavour == "generic":
+        extra["vehicle_params"] = P.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3)
+    mk = lambda: MarineVecEnv(kind, n, seed=3, flow=flow, maxSteps=7, **kw, **extra)   # 24 steps cross three resets
+    a, b = mk(), mk()
+    if flavour:
+        assert flavour in a.variant
+    a.reset_tensors(); b.reset_tensors()
+    adim = a.action_space.shape[0]
+    act = torch.rand((reps, K, n, adim), device="cuda") * 2 - 1
+    for r in range(reps):
+        ob, rb, db = b.rollout_tensors(act[r])
+        for k in range(K):
+            oa, ra, da = a.step_tensors(act[r, k])
+            assert torch.equal(oa, ob[k]) and torch.equal(ra, rb[k]) and torch.equal(da, db[k]), (r, k)
+    assert np.array_equal(a.get_state(), b.get_state())
+    a.close(); b.close()
