@@ -265,6 +265,8 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    if pd_obj is not None and world > 1:
+        dist.all_reduce(pd_steps)          # whole-job env steps
 
     obs_t, _, _ = env._ensure_tensors()
     finite = bool(torch.isfinite(obs_t).all().item())
