@@ -174,7 +174,8 @@ struct Rhs3 {
 };
 
 
-template <class PP, bool ZOH, bool FLOW, int INTEG>
+// MULTI: io.k_steps consecutive env steps per launch (mvrl_rollout_dev), see rov6_step_kernel
+template <class PP, bool ZOH, bool FLOW, int INTEG, bool MULTI = false>
 __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
     const uint32_t i_in = blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
@@ -182,7 +183,16 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     const uint32_t n32 = (uint32_t)io.n;  // see mvrl_rov6.hip: 32-bit byte offsets -> saddr addressing
     char* const stb = reinterpret_cast<char*>(io.state);
 #define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) * (uint32_t)sizeof(float))))
-#define LANE i_in
+#define LANE i_k
+    const int k_steps = MULTI ? io.k_steps : 1;
+#pragma nounroll
+    for (int kstep = 0; kstep < k_steps; kstep++) {
+    const float* const actions_k = (MULTI && io.actions) ? io.actions + (size_t)kstep * (size_t)io.n * 3 : io.actions;
+    float* const obs_k = MULTI ? io.obs + (size_t)kstep * (size_t)io.n * 5 : io.obs;
+    float* const reward_k = MULTI ? io.reward + (size_t)kstep * (size_t)io.n : io.reward;
+    uint8_t* const done_k = MULTI ? io.done + (size_t)kstep * (size_t)io.n : io.done;
+    uint32_t i_k = i_in;
+    if (MULTI) asm volatile("" : "+v"(i_k));
     float y[6], sp[3], path[4];
     Pid3 pid;
     // load order as in mvrl_rov6.hip: what the turbulence gathers depend on first, everything else behind it,
@@ -198,7 +208,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     for (int k = 0; k < 3; k++) { pid.eold[k] = ST(R3_EOLD + k); pid.eint[k] = ST(R3_EINT + k); }
     float spin[3];
     {
-        const float* arow = io.fixed_sp ? nullptr : io.actions + (size_t)i_in * 3;
+        const float* arow = io.fixed_sp ? nullptr : actions_k + (size_t)i_in * 3;
 #pragma unroll
         for (int k = 0; k < 3; k++) spin[k] = io.fixed_sp ? ST(R3_SP + k) : arow[k];
     }
@@ -292,8 +302,8 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     float o[5];
     observe3(p, y, path, sp, o);
     const bool done = istep >= io.max_steps;
-    io.reward[i] = 0.f;
-    io.done[i] = done ? 3 : 0;  // bit 0 = done, bit 1 = time limit
+    reward_k[i] = 0.f;
+    done_k[i] = done ? 3 : 0;  // bit 0 = done, bit 1 = time limit
     if (done && io.auto_reset) {
         if (io.term_obs) {
 #pragma unroll
@@ -317,7 +327,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
         observe3(p, y, path, sp, o);
     }
 #pragma unroll
-    for (int q = 0; q < 5; q++) io.obs[(size_t)i * 5 + q] = o[q];
+    for (int q = 0; q < 5; q++) obs_k[(size_t)i * 5 + q] = o[q];
 #pragma unroll
     for (int k = 0; k < 6; k++) ST(R3_Y + k) = y[k];
 #pragma unroll
@@ -327,6 +337,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
         for (int k = 0; k < 3; k++) ST(R3_SP + k) = sp[k];
     }
     ST(R3_ISTEP) = pack_int(istep);
+    }  // kstep
 #undef ST
 #undef LANE
 }
@@ -415,6 +426,18 @@ hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& f
         return hipGetLastError();
     }
 #endif
+    if (io.k_steps > 1) {  // fused multi-step launch
+#define MVRL_L3M(PPT, Z, F) hipLaunchKernelGGL((rov3_step_kernel<PPT, Z, F, 0, true>), grid, block, 0, stream, p, io, fl)
+        if (baked) {
+            if (zoh) { if (flow) MVRL_L3M(const Rov3Baked*, true, true); else MVRL_L3M(const Rov3Baked*, true, false); }
+            else { if (flow) MVRL_L3M(const Rov3Baked*, false, true); else MVRL_L3M(const Rov3Baked*, false, false); }
+        } else {
+            if (zoh) { if (flow) MVRL_L3M(CP3, true, true); else MVRL_L3M(CP3, true, false); }
+            else { if (flow) MVRL_L3M(CP3, false, true); else MVRL_L3M(CP3, false, false); }
+        }
+#undef MVRL_L3M
+        return hipGetLastError();
+    }
     if (baked) {
         if (zoh) { if (flow) MVRL_L3(const Rov3Baked*, true, true); else MVRL_L3(const Rov3Baked*, true, false); }
         else { if (flow) MVRL_L3(const Rov3Baked*, false, true); else MVRL_L3(const Rov3Baked*, false, false); }
