@@ -395,6 +395,12 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
     const uint32_t i_in = blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
     if (i_in >= (uint32_t)io.n) return;
     const int k_steps = MULTI ? io.k_steps : 1;
+    // the env's state: loaded before the first step of a launch and stored after the last one - in a fused launch it
+    // stays in registers in between
+    float y[12], sp[6], path[6];
+    Pid6 pid;
+    int istep = 0;
+    float toff = 0.f;
 #pragma nounroll
     for (int kstep = 0; kstep < k_steps; kstep++) {
     const float* const actions_k = (MULTI && io.actions) ? io.actions + (size_t)kstep * (size_t)io.n * 6 : io.actions;
@@ -412,21 +418,20 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
 #define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) * (uint32_t)sizeof(float))))
 #define LANE i_k
 
-    float y[12], sp[6], path[6];
-    Pid6 pid;
     // Issue order matters: vector loads return in order, and the turbulence gathers (a second, dependent HBM round
     // trip) need only x, y, iStep and the time offset - so those four go first and the gathers can leave while the rest
     // of the state is still arriving.  A load placed behind the set-point branch below would cost a third round trip
     // (tools/stamp_probe.py measures the phases).
-    y[0] = ST(R6_Y + 0); y[1] = ST(R6_Y + 1);
-    int istep = unpack_int(ST(R6_ISTEP));
-    float toff = 0.f;
-    if (FLOW) toff = ST(R6_TOFF);
-    asm volatile("" ::: "memory");  // keep the four critical loads first in issue order
+    if (!MULTI || kstep == 0) {
+        y[0] = ST(R6_Y + 0); y[1] = ST(R6_Y + 1);
+        istep = unpack_int(ST(R6_ISTEP));
+        if (FLOW) toff = ST(R6_TOFF);
+        asm volatile("" ::: "memory");  // keep the four critical loads first in issue order
 #pragma unroll
-    for (int k = 2; k < 12; k++) y[k] = ST(R6_Y + k);
+        for (int k = 2; k < 12; k++) y[k] = ST(R6_Y + k);
 #pragma unroll
-    for (int k = 0; k < 6; k++) { pid.eold[k] = ST(R6_EOLD + k); pid.eint[k] = ST(R6_EINT + k); }
+        for (int k = 0; k < 6; k++) { pid.eold[k] = ST(R6_EOLD + k); pid.eint[k] = ST(R6_EINT + k); }
+    }
     // set-point inputs, branch-free (one basic block up to the RK4 loop lets the gathers leave before anything waits
     // on the bulk of the state): fixed set-point -> the stored planes (6DoF.py:536-541), else the action row
     float spin[6];
@@ -563,14 +568,13 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
 #pragma unroll
             for (int q = 0; q < 9; q++) io.term_obs[(size_t)i * 9 + q] = o[q];
         }
-        float ang[3], toff;
+        float ang[3];
         const int episode = unpack_int(ST(R6_EPISODE)) + 1;
         ST(R6_EPISODE) = pack_int(episode);
         if (io.fixed_sp) {
-            // reset(initialSetpoint=sp) keeps the set-point: path/sp stay (6DoF.py:500-511)
+            // reset(initialSetpoint=sp) keeps the set-point: path/sp stay (6DoF.py:500-511), and so does the time offset
 #pragma unroll
             for (int q = 0; q < 3; q++) { ang[q] = sp[3 + q]; }
-            toff = FLOW ? ST(R6_TOFF) : 0.f;
         } else {
             random_init6(io.seed, io.env_offset + (int64_t)i, (uint32_t)episode, fl.t_quarter, path, ang, toff);
 #pragma unroll
@@ -587,15 +591,17 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
     }
 #pragma unroll
     for (int q = 0; q < 9; q++) obs_k[(size_t)i * 9 + q] = o[q];
+    if (!MULTI || kstep == k_steps - 1) {
 #pragma unroll
-    for (int k = 0; k < 12; k++) ST(R6_Y + k) = y[k];
+        for (int k = 0; k < 12; k++) ST(R6_Y + k) = y[k];
 #pragma unroll
-    for (int k = 0; k < 6; k++) { ST(R6_EOLD + k) = pid.eold[k]; ST(R6_EINT + k) = pid.eint[k]; }
-    if (!io.fixed_sp) {
+        for (int k = 0; k < 6; k++) { ST(R6_EOLD + k) = pid.eold[k]; ST(R6_EINT + k) = pid.eint[k]; }
+        if (!io.fixed_sp) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) ST(R6_SP + k) = sp[k];
+            for (int k = 0; k < 6; k++) ST(R6_SP + k) = sp[k];
+        }
+        ST(R6_ISTEP) = pack_int(istep);
     }
-    ST(R6_ISTEP) = pack_int(istep);
 #ifdef MVRL_STAMP_ON
     STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)");
