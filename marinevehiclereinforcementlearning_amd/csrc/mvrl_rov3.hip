@@ -185,6 +185,11 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
 #define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) * (uint32_t)sizeof(float))))
 #define LANE i_k
     const int k_steps = MULTI ? io.k_steps : 1;
+    // state: loaded before the first step of a launch, stored after the last, in registers in between (mvrl_rov6.hip)
+    float y[6], sp[3], path[4];
+    Pid3 pid;
+    int istep = 0;
+    float toff = 0.f;
 #pragma nounroll
     for (int kstep = 0; kstep < k_steps; kstep++) {
     const float* const actions_k = (MULTI && io.actions) ? io.actions + (size_t)kstep * (size_t)io.n * 3 : io.actions;
@@ -193,19 +198,18 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     uint8_t* const done_k = MULTI ? io.done + (size_t)kstep * (size_t)io.n : io.done;
     uint32_t i_k = i_in;
     if (MULTI) asm volatile("" : "+v"(i_k));
-    float y[6], sp[3], path[4];
-    Pid3 pid;
     // load order as in mvrl_rov6.hip: what the turbulence gathers depend on first, everything else behind it,
     // branch-free up to the RK4 loop so that the gathers leave before the bulk of the state is waited on
-    y[0] = ST(R3_Y + 0); y[1] = ST(R3_Y + 1);
-    int istep = unpack_int(ST(R3_ISTEP));
-    float toff = 0.f;
-    if (FLOW) toff = ST(R3_TOFF);
-    asm volatile("" ::: "memory");
+    if (!MULTI || kstep == 0) {
+        y[0] = ST(R3_Y + 0); y[1] = ST(R3_Y + 1);
+        istep = unpack_int(ST(R3_ISTEP));
+        if (FLOW) toff = ST(R3_TOFF);
+        asm volatile("" ::: "memory");
 #pragma unroll
-    for (int k = 2; k < 6; k++) y[k] = ST(R3_Y + k);
+        for (int k = 2; k < 6; k++) y[k] = ST(R3_Y + k);
 #pragma unroll
-    for (int k = 0; k < 3; k++) { pid.eold[k] = ST(R3_EOLD + k); pid.eint[k] = ST(R3_EINT + k); }
+        for (int k = 0; k < 3; k++) { pid.eold[k] = ST(R3_EOLD + k); pid.eint[k] = ST(R3_EINT + k); }
+    }
     float spin[3];
     {
         const float* arow = io.fixed_sp ? nullptr : actions_k + (size_t)i_in * 3;
@@ -312,7 +316,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
         const int episode = unpack_int(ST(R3_EPISODE)) + 1;
         ST(R3_EPISODE) = pack_int(episode);
         if (!io.fixed_sp) {
-            float heading, toff;
+            float heading;
             random_init3(io.seed, io.env_offset + (int64_t)i, (uint32_t)episode, fl.t_quarter, path, heading, toff);
 #pragma unroll
             for (int q = 0; q < 4; q++) ST(R3_PATH + q) = path[q];
@@ -328,15 +332,17 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     }
 #pragma unroll
     for (int q = 0; q < 5; q++) obs_k[(size_t)i * 5 + q] = o[q];
+    if (!MULTI || kstep == k_steps - 1) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) ST(R3_Y + k) = y[k];
+        for (int k = 0; k < 6; k++) ST(R3_Y + k) = y[k];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { ST(R3_EOLD + k) = pid.eold[k]; ST(R3_EINT + k) = pid.eint[k]; }
-    if (!io.fixed_sp) {
+        for (int k = 0; k < 3; k++) { ST(R3_EOLD + k) = pid.eold[k]; ST(R3_EINT + k) = pid.eint[k]; }
+        if (!io.fixed_sp) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) ST(R3_SP + k) = sp[k];
+            for (int k = 0; k < 3; k++) ST(R3_SP + k) = sp[k];
+        }
+        ST(R3_ISTEP) = pack_int(istep);
     }
-    ST(R3_ISTEP) = pack_int(istep);
     }  // kstep
 #undef ST
 #undef LANE
