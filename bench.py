@@ -33,8 +33,8 @@ WORKLOADS = {
     "c4": dict(model="rov6", n=1048576, flow=True, bytes=365, io=129, name="6-DoF + turbulence, 1 048 576 envs per GPU (BASELINE configs[3]; x8 = configs[4])"),
     "c3": dict(model="rov6", n=262144, flow=False, bytes=297, io=65, name="6-DoF, 262 144 envs (BASELINE configs[2])"),
     "c2": dict(model="rov3", n=65536, flow=False, bytes=165, io=37, name="3-DoF, 65 536 envs (BASELINE configs[1])"),
-    "auv": dict(model="auv", n=1048576, flow=True, bytes=389, name="AuvEnv + turbulence, 1 048 576 envs"),
-    "auvcyl": dict(model="auv_cyl", n=1048576, flow=True, bytes=397, name="AuvEnvCyl (way-points) + turbulence, 1 048 576 envs"),
+    "auv": dict(model="auv", n=1048576, flow=True, bytes=389, io=125, name="AuvEnv + turbulence, 1 048 576 envs"),
+    "auvcyl": dict(model="auv_cyl", n=1048576, flow=True, bytes=397, io=125, name="AuvEnvCyl (way-points) + turbulence, 1 048 576 envs"),
     # the chain either side of the path, device-resident: PD policy -> AuvEnv step -> symmetry replay-buffer add (x5)
     # bytes: what must touch HBM if every inter-kernel tensor (obs, action, reward, done) stayed on chip: AuvEnv state
     # read + write + flow gathers (328) + the five ring-slot writes (550)

@@ -223,9 +223,10 @@ int mvrl_get_terminal_obs(mvrl_handle* h, float* obs);
 int mvrl_get_terminal_obs_f64(mvrl_handle* h, double* obs);
 /* k_steps consecutive env steps in one call: actions_dev [k][n][act_dim], obs_dev [k][n][obs_dim], reward_dev [k][n],
  * done_dev [k][n] (device pointers, the handle's precision) - the results of k mvrl_step_dev calls, auto-resets included.
- * For open-loop roll-outs (random / recorded / action-repeat actions: BASELINE's "random-action rollouts"); the fp32 3-DoF
- * kernels and the 6-DoF kernels with the reference's structure run all k steps in ONE launch (no inter-launch gap, state
- * re-read from L2), everything else is stepped launch by launch.  The terminal-observation buffer keeps the LAST termination of each env. */
+ * For open-loop roll-outs (random / recorded / action-repeat actions: BASELINE's "random-action rollouts"); the fp32 kernels
+ * (6-DoF: those with the reference's structure) run all k steps in ONE launch with the env state in registers between
+ * the steps; everything else is stepped launch by launch.  Rigid-body results equal k single steps bit for bit, AuvEnv's
+ * to fp32 rounding.  The terminal-observation buffer keeps the LAST termination of each env. */
 int mvrl_rollout_dev(mvrl_handle* h, const void* actions_dev, void* obs_dev, void* reward_dev, uint8_t* done_dev, int32_t k_steps,
                      void* stream);
 int mvrl_get_terminal_obs_dev(mvrl_handle* h, void* obs_dev, void* stream);

@@ -373,7 +373,70 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_reset_kernel(const AuvDev p, f
     }
 }
 
+// io.k_steps consecutive AuvEnv steps per launch (mvrl_rollout_dev): actions[k] -> obs[k] / reward[k] / done[k], the
+// lane's 55 words in registers from the first step to the last.  Same auv_step_core and the same reset sequence as
+// auv_step_kernel; being a different kernel it may round the last bit differently (fast-math), so its results are those of
+// k_steps single-step launches to fp32 rounding, not bit for bit (the rigid-body kernels, one template for both, are).
+template <bool FLOW>
+__global__ __launch_bounds__(MVRL_BLOCK) void auv_rollout_kernel(const AuvDev p, const StepIO io, const FlowDev fl) {
+    const uint32_t i = blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= (uint32_t)io.n) return;
+    const uint32_t n32 = (uint32_t)io.n;
+    char* const stb = reinterpret_cast<char*>(io.state);
+#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) * (uint32_t)sizeof(float))))
+    const bool cyl = p.n_wp > 0;
+    AuvLane s;
+    MVRL_AUV_LOAD_LANE(s);
+    const size_t n = (size_t)io.n;
+#pragma nounroll
+    for (int k = 0; k < io.k_steps; k++) {
+        const float* ap = io.actions + ((size_t)k * n + i) * 3;
+        AuvStepOut out;
+        auv_step_core<FLOW>(p, fl, s, ap[0], ap[1], ap[2], io.dt, io.max_steps, out);
+        io.reward[(size_t)k * n + i] = out.reward;
+        io.done[(size_t)k * n + i] = out.done ? (out.time_up ? 3 : 1) : 0;
+        if (out.done && io.auto_reset) {
+            if (io.term_obs) {
+#pragma unroll
+                for (int q = 0; q < 11; q++) io.term_obs[(size_t)i * 11 + q] = out.o[q];
+            }
+            float v[16];
+            const int episode = unpack_int(ST(AV_EPISODE)) + 1;
+            ST(AV_EPISODE) = pack_int(episode);
+            random_init_auv(p, io.seed, io.env_offset + (int64_t)i, (uint32_t)episode, fl.t_quarter, v);
+            s.x = v[0]; s.y = v[1]; s.psi = v[2]; s.vx = 0.f; s.vy = 0.f; s.r = 0.f;
+            if (!cyl) s.tgt = v[3];
+            s.toff = v[4];
+#pragma unroll
+            for (int q = 0; q < 11; q++) s.mu[q] = v[5 + q];
+            s.perr_ox = s.tx - s.x; s.perr_oy = s.ty - s.y; s.herr_o = angle_error(s.tgt, s.psi);
+            s.istep = 0;
+            observe_auv(p, s.x, s.y, s.psi, s.vx, s.vy, s.r, s.tx, s.ty, s.tgt, s.herr_o, s.perr_ox, s.perr_oy, out.o);
+        }
+        float* orow = io.obs + ((size_t)k * n + i) * 11;
+#pragma unroll
+        for (int q = 0; q < 11; q++) orow[q] = out.o[q];
+    }
+    ST(AV_X) = s.x; ST(AV_Y) = s.y; ST(AV_PSI) = s.psi; ST(AV_VX) = s.vx; ST(AV_VY) = s.vy; ST(AV_R) = s.r;
+    ST(AV_HERR_O) = s.herr_o; ST(AV_PERR_O) = s.perr_ox; ST(AV_PERR_O + 1) = s.perr_oy;
+    ST(AV_TGT) = s.tgt;
+    if (cyl) ST(AV_IWP) = pack_int(s.iwp);
+#pragma unroll
+    for (int q = 0; q < 11; q++) ST(AV_MULT + q) = s.mu[q];
+    if (FLOW) ST(AV_TOFF) = s.toff;
+#pragma unroll
+    for (int q = 0; q < 30; q++) ST(AV_HIST + q) = s.hist[q];
+    ST(AV_ISTEP) = pack_int(s.istep);
+#undef ST
+}
+
 hipError_t launch_auv_step(const AuvDev& p, const StepIO& io, const FlowDev& fl, bool flow, hipStream_t stream) {
+    dim3 grid_r((unsigned)((io.n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block_r(MVRL_BLOCK);
+    if (io.k_steps > 1) {
+        if (flow) hipLaunchKernelGGL((auv_rollout_kernel<true>), grid_r, block_r, 0, stream, p, io, fl);
+        else hipLaunchKernelGGL((auv_rollout_kernel<false>), grid_r, block_r, 0, stream, p, io, fl);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((io.n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
     if (flow) hipLaunchKernelGGL((auv_step_kernel<true>), grid, block, 0, stream, p, io, fl);
     else hipLaunchKernelGGL((auv_step_kernel<false>), grid, block, 0, stream, p, io, fl);

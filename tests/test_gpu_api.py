@@ -520,10 +520,12 @@ def test_fused_pd_episodes_equal_step_by_step(kind, n_steps):
 
 
 @pytest.mark.parametrize("kind,kw", [("rov6", dict()), ("rov6", dict(control_mode="zoh")), ("rov6", dict(flavour="sym")),
-                                     ("rov6", dict(flavour="generic")), ("rov3", dict()), ("auv", dict())])
+                                     ("rov6", dict(flavour="generic")), ("rov3", dict()), ("auv", dict()),
+                                     ("auv", dict(noiseMagCoeffs=0.1, noiseMagActuation=0.1)), ("auv_cyl", dict(maxSteps=9))])
 def test_rollout_equals_k_steps(kind, kw):
     """mvrl_rollout_dev / MarineVecEnv.rollout_tensors: K env steps per call == K step_tensors calls, bit for bit, random
-    auto-resets included - fused into one launch for the fp32 6-DoF baked / sym kernels, launch by launch otherwise."""
+    auto-resets included (rigid-body models; AuvEnv to fp32 rounding) - one fused launch except for the generic 6-DoF
+    flavour, which is stepped launch by launch."""
     n, K, reps = 3000, 6, 4
     flow = ReconstructedFlow.synthetic(n_modes=4, n_time=128, device=0)
     flow.scale(11., 1., 2., translate=(-1.65, -1.1))
@@ -534,17 +536,33 @@ def test_rollout_equals_k_steps(kind, kw):
         extra["vehicle_params"] = P.rov6_params(m=12.0, Xuu=-19.0)
     if flavour == "generic":
         extra["vehicle_params"] = P.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3)
-    mk = lambda: MarineVecEnv(kind, n, seed=3, flow=flow, maxSteps=7, **kw, **extra)   # 24 steps cross three resets
+    kw.setdefault("maxSteps", 7)                                                       # 24 steps cross three resets
+    mk = lambda: MarineVecEnv(kind, n, seed=3, flow=flow, **kw, **extra)
     a, b = mk(), mk()
     if flavour:
         assert flavour in a.variant
     a.reset_tensors(); b.reset_tensors()
     adim = a.action_space.shape[0]
     act = torch.rand((reps, K, n, adim), device="cuda") * 2 - 1
+    split = torch.zeros(n, dtype=torch.bool, device="cuda")
     for r in range(reps):
         ob, rb, db = b.rollout_tensors(act[r])
         for k in range(K):
             oa, ra, da = a.step_tensors(act[r, k])
-            assert torch.equal(oa, ob[k]) and torch.equal(ra, rb[k]) and torch.equal(da, db[k]), (r, k)
-    assert np.array_equal(a.get_state(), b.get_state())
+            if kind.startswith("auv"):
+                # AuvEnv's fused roll-out is a separate kernel around the same device functions: equal to fp32 rounding.
+                # A lane within that of a bound / way-point threshold may end an episode one step apart; it is dropped
+                # from the comparison from then on (and counted).
+                split |= (da != db[k])
+                if kind == "auv_cyl":   # ... or switch way-point a step apart (the scaled "V0" observation then jumps)
+                    split |= (oa - ob[k]).abs().amax(dim=1) > 1e-3
+                ok = ~split
+                assert float((oa[ok] - ob[k][ok]).abs().max()) < (2e-4 if kind == "auv_cyl" else 2e-5), (r, k)
+                assert float(((ra[ok] - rb[k][ok]).abs() / ra[ok].abs().clamp(min=1.0)).max()) < 2e-5, (r, k)
+            else:
+                assert torch.equal(oa, ob[k]) and torch.equal(ra, rb[k]) and torch.equal(da, db[k]), (r, k)
+    if kind.startswith("auv"):
+        assert float(split.float().mean()) < 0.005, int(split.sum())
+    else:
+        assert np.array_equal(a.get_state(), b.get_state())
     a.close(); b.close()
