@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
 """Benchmark of the environment hot path: synthetic random-action roll-outs of the fused HIP step kernel.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|auv] [--gather root|all|none]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c2|auv] [--chains C] [--gather root|all|none]
 
-One "step" = one env step of every environment of the batch = one launch of the fused step kernel per GPU.
+One "step" = one env step of every environment of the batch: one launch of the fused step kernel per GPU with
+`--chains 1`, C launches over C lane ranges on C streams otherwise (default 2 - chains.ChainStepper: the sub-batches are
+independent, so each chain's next launch only waits for its own previous one and the other chain's kernel covers the
+launch gap, ramp and tail).  Timing: after a stated pre-warm (>= --prewarm-s seconds of the same steps, so that the
+shader clock has settled) and W warm-up steps, the K-step timed region - bracketed by barrier + synchronize - is repeated
+--repeats times; `ms_per_step` / `value` are the MEDIAN repeat (max over ranks per repeat), all repeats are in the line.
 `value` is the sharded hot path with outputs left in each rank's HBM (the same thing at every N); for N > 1 the
 RCCL gather of observations/rewards/dones to rank 0 that BASELINE.json's 8-GPU config names is run and timed over the
 same K steps and reported beside it as `with_gather` (root ingest is xGMI-link-bound).  Workloads (BASELINE.json configs):
@@ -48,6 +53,8 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 RING = 8
+N_SIMD = 256 * 4        # CUs x SIMDs
+VALU_PEAK = 1.2         # wave64 VALU instructions / ns / SIMD: one per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
 XGMI_LINK_GBS = 76.8  # one xGMI link, one direction (7 links x ~153 GB/s bidirectional per GPU)
 
 
@@ -95,8 +102,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     # Defaults sized for steady state: the chip needs ~0.1 s under load before its shader clock settles (a 200-step
     # run measures 145 us/launch, 2000 steps and more 133 us on the same device)
-    ap.add_argument("--steps", type=int, default=5000)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is repeated this many times; the median is reported")
+    ap.add_argument("--prewarm-s", type=float, default=0.4, help="seconds of untimed steps before the warm-up (clock settling)")
+    ap.add_argument("--chains", type=int, default=2, help="independent lane-range chains per step (1 = one launch per step on one stream)")
+    ap.add_argument("--no-stagger", action="store_true", help="do not offset the chains' first launches")
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--rollout", action="store_true", help="step through mvrl_rollout_dev: the RING action batches per call "
@@ -182,6 +193,14 @@ def main():
         EP = 250
         pd_steps = torch.zeros((), dtype=torch.int64, device=dev)     # env steps actually taken (episodes may end early)
 
+    use_chains = (args.chains > 1 and loop_objs is None and pd_obj is None and not args.rollout and not args.graph)
+    stepper = None
+    if use_chains:
+        from marinevehiclereinforcementlearning_amd.chains import ChainStepper
+        stepper = ChainStepper(env, n_chains=args.chains, stagger=not args.no_stagger)
+    if (args.rollout or args.graph) and (K % RING or W % RING):
+        sys.exit(f"--rollout / --graph run {RING} env steps per call: --steps and --warmup must be multiples of {RING}")
+
     def run_plain(steps):
         if pd_obj is not None:
             # `steps` env steps = steps / 250 launches of whole episodes (reset + one fused launch each)
@@ -198,14 +217,20 @@ def main():
                 buf.add(st[0], nobs, act, rew, done)
                 st[0].copy_(nobs)
             return
-        if roll_out is not None and steps % RING == 0:
+        if roll_out is not None:
             for _ in range(steps // RING):
                 env.rollout_tensors(ring, out=roll_out)
             return
-        if graph is not None and steps % RING == 0:
+        if graph is not None:
             for _ in range(steps // RING):
                 graph.replay()
             h.count_launches(steps)
+            return
+        if stepper is not None:
+            stepper.fork()
+            for k in range(steps):
+                stepper.step(ring[k % RING])
+            stepper.join()
             return
         for k in range(steps):
             env.step_tensors(ring[k % RING])
@@ -218,7 +243,7 @@ def main():
         roll_out = (torch.empty((RING, n, obs_dim), dtype=rt, device=dev), torch.empty((RING, n), dtype=rt, device=dev),
                     torch.empty((RING, n), dtype=torch.uint8, device=dev))
     graph = None
-    if args.graph and loop_objs is None:
+    if args.graph and loop_objs is None and roll_out is None:
         # one HIP graph of RING consecutive step launches (the env's RNG position lives in its state, so a replay is
         # exactly the next RING steps); captured on a side stream as torch requires
         cap = torch.cuda.Stream(device=dev)
@@ -233,42 +258,52 @@ def main():
     if world > 1 and args.gather != "none" and args.precision == "f32":   # the gather message is an fp32 format
         gather = [D.OutputGather(world * n, obs_dim, dev, mode=args.gather) for _ in range(2)]
         side = torch.cuda.Stream(device=dev)
-        ev_step = [torch.cuda.Event() for _ in range(2)]
-        ev_gather = [torch.cuda.Event() for _ in range(2)]
+        pipe = D.GatherPipeline(gather, side)
 
     def run_gather(steps):
-        main = torch.cuda.current_stream()
         for k in range(steps):
-            b = k & 1
-            if k >= 2:
-                main.wait_event(ev_gather[b])          # buffer b is free again once gather k-2 has finished
-            env.step_tensors(ring[k % RING], out=gather[b].out_views())   # kernel writes the message in place
-            ev_step[b].record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ev_step[b])
-                gather[b].exchange()
-                ev_gather[b].record(side)
-        main.wait_stream(side)
+            pipe.step(lambda out, k=k: env.step_tensors(ring[k % RING], out=out))
+        pipe.drain()
 
-    # ---- warm-up, then the timed region: EXACTLY K steps of the sharded hot path between barrier+synchronize pairs.
-    # Outputs stay in the HBM of the rank that produced them, exactly as at N = 1 (where handing them to a host
-    # consumer over PCIe is not part of `value` either); the per-step RCCL gather to rank 0 is timed separately below.
+    # ---- stated pre-warm, warm-up, then the timed region: EXACTLY K steps of the sharded hot path between
+    # barrier+synchronize pairs, repeated; the median repeat is reported.  Outputs stay in the HBM of the rank that
+    # produced them, exactly as at N = 1 (where handing them to a host consumer over PCIe is not part of `value` either);
+    # the per-step RCCL gather to rank 0 is timed separately below.
+    chunk = RING * (EP if pd_obj is not None else 1)
+    t_pre = time.perf_counter()
+    pre_steps = 0
+    while True:
+        run_plain(chunk * 8)
+        pre_steps += chunk * 8
+        torch.cuda.synchronize()
+        if time.perf_counter() - t_pre >= args.prewarm_s:
+            break
+    prewarm_s = time.perf_counter() - t_pre
     run_plain(W)
     sync()
-    if pd_obj is not None:
-        pd_steps.zero_()
-    h.timing_begin(stream)
-    t0 = time.perf_counter()
-    run_plain(K)
-    kern_ms, launches = h.timing_end(stream)
-    sync()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    if pd_obj is not None and world > 1:
-        dist.all_reduce(pd_steps)          # whole-job env steps
+    reps = []
+    for r in range(max(1, args.repeats)):
+        if pd_obj is not None:
+            pd_steps.zero_()
+        sync()
+        h.timing_begin(stream)
+        t0 = time.perf_counter()
+        run_plain(K)
+        kern_ms, launches = h.timing_end(stream)
+        sync()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        psteps = None
+        if pd_obj is not None:
+            if world > 1:
+                dist.all_reduce(pd_steps)          # whole-job env steps
+            psteps = float(pd_steps.item())
+        reps.append(dict(elapsed=float(t.item()), kern_ms=kern_ms, launches=launches, pd_steps=psteps))
+    order = sorted(range(len(reps)), key=lambda i: reps[i]["elapsed"])
+    med = reps[order[len(order) // 2]]
+    elapsed, kern_ms, launches = med["elapsed"], med["kern_ms"], med["launches"]
 
     obs_t, _, _ = env._ensure_tensors()
     finite = bool(torch.isfinite(obs_t).all().item())
@@ -276,79 +311,119 @@ def main():
     out = None
     if rank == 0:
         value = world * n * K / elapsed
+        steps_per_region = K
         if pd_obj is not None:   # whole episodes per launch: count the env steps that were really taken
-            value = float(pd_steps.item()) / elapsed
-            wl["bytes"] = wl["bytes"] * float(pd_steps.item()) / max(1, launches) / n   # algorithmic bytes per env per LAUNCH
-        per_launch_s = kern_ms * 1e-3 / max(1, launches)
-        achieved = wl["bytes"] * n / per_launch_s / 1e9
-        traffic = None
-        tp = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+            value = med["pd_steps"] / elapsed
+            steps_per_region = med["pd_steps"] / (world * n)
+        # HIP events on the launch stream bracket the K steps of the median repeat: time per env step of the batch.
+        # (With chains the begin event is recorded before the chains fork and the end event after they have joined.)
+        per_step_s = kern_ms * 1e-3 / max(1e-9, steps_per_region)
+        achieved = wl["bytes"] * n / per_step_s / 1e9
+        khash = build.source_hash()
+        traffic, traffic_src, valu = None, None, None
+        tp = os.path.join(REPO, "profiles", "r02_counters.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch") if n == wl["n"] else None
+                ent = tj.get("workloads", {}).get(args.workload)
+                # counters describe ONE build of the kernels: dropped when the kernel sources have changed since
+                if ent and tj.get("kernel_source_hash") == khash and n == wl["n"] and args.precision == "f32" \
+                        and args.control_mode == "faithful" and args.n_substeps == 4 and not args.rollout:
+                    traffic = ent.get("hbm_bytes_per_step")
+                    traffic_src = {"file": "profiles/r02_counters.json", "kernel_source_hash": khash, "commit": tj.get("commit")}
+                    if "valu" in ent:
+                        v = dict(ent["valu"])
+                        # achieved VALU issue rate of THIS run from the committed instruction count and the live time
+                        wave_instr = v["wave_instr_per_env_step"] * n / 64.0
+                        rate = wave_instr / (per_step_s * 1e9) / N_SIMD          # wave-instr / ns / SIMD
+                        v.update({"achieved": rate, "peak": VALU_PEAK, "unit": "wave-instr/ns/SIMD", "frac": rate / VALU_PEAK,
+                                  "flops_per_env_step": v.get("flops_per_env_step"),
+                                  "achieved_TFLOPs": (v.get("flops_per_env_step") or 0) * n / per_step_s / 1e12})
+                        valu = v
             except Exception:  # noqa: BLE001
                 traffic = None
+        launch_desc = ("one launch per 250-step episode batch" if pd_obj is not None else
+                       "mvrl_rollout_dev: %d env steps per call" % RING if roll_out is not None else
+                       "hip graph of %d steps" % RING if graph is not None else
+                       "%d chains of lane ranges on %d streams (mvrl_step_range_dev), %d launches per step%s" %
+                       (stepper.n_chains, stepper.n_chains, stepper.n_chains, "" if args.no_stagger else ", first launches staggered")
+                       if stepper is not None else "one launch per step")
         out = {
             "metric": "env-steps/sec (whole node) + achieved HBM GB/s, 6-DoF batch", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "timing": {"repeats": len(reps), "statistic": "median repeat of the K-step region (max over ranks per repeat)",
+                       "ms_per_step_repeats": [r_["elapsed"] / K * 1e3 for r_ in reps],
+                       "prewarm_s": prewarm_s, "prewarm_steps": pre_steps},
             "config": {"workload": wl["name"], "envs_per_gpu": n, "global_envs": world * n, "dt": 0.02 if wl["model"].startswith("auv") else 0.2,
                        "n_substeps": args.n_substeps, "control_mode": args.control_mode, "episode_len": 250,
                        "kernel": env.variant,
                        "actions": ("PDController evaluated inside the episode kernel" if pd_obj is not None else
                                    "PDController kernel on the previous observation" if loop_objs is not None else
                                    f"ring of {RING} pre-generated uniform(-1,1) batches in HBM"),
-                       "launch": ("one launch per 250-step episode batch" if pd_obj is not None else
-                                  "mvrl_rollout_dev: %d env steps per call" % RING if roll_out is not None else
-                                  "hip graph of %d steps" % RING if graph is not None else "one launch per step"),
+                       "launch": launch_desc,
                        "collective_in_value": "none: shards are independent, outputs stay in each rank's HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_us_per_launch": per_launch_s * 1e6, "algorithmic_bytes_per_env_step": wl["bytes"],
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_us_per_step": per_step_s * 1e6, "kernel_launches_per_step": launches / max(1e-9, steps_per_region),
+                         "algorithmic_bytes_per_env_step": wl["bytes"], "valu": valu, "kernel_source_hash": khash,
                          "note": ("fused episodes: the bytes are the turbulence gathers (L2 / Infinity-Cache resident), the kernel is "
                                   "bound by instruction issue, not HBM" if pd_obj is not None else
                                   "HBM-bound kernel" if wl["model"].startswith("auv") else
-                                  "VALU-issue/power-bound kernel (~7 k lane-ops per env step for 6-DoF); HBM fraction reported as "
-                                  "the contract asks") + "; kernel_us_per_launch = HIP-event time of the timed region / launches "
-                                 "(includes the ~4 us inter-launch gap rocprof's per-kernel average leaves out)"},
+                                  "the binding roof of this kernel is VALU issue (`valu`); the HBM fraction is reported as the "
+                                  "contract asks") + "; kernel_us_per_step = HIP-event time of the median K-step region / K "
+                                 "(wall time on the GPU: launch gaps, ramps and tails included)"},
             "outputs_finite": finite,
         }
+        if world > 1:
+            out["rccl"] = D.rccl_info(backend, local_rank)
 
     if gather is not None:
         # The same K steps with BASELINE configs[4]'s exchange: every rank's (obs, reward, done) message gathered to
         # rank 0 each step over RCCL/xGMI, overlapped with the next step.  Root ingest is link-bound.
-        # A watchdog keeps the primary result if the collective stalls: the line is printed without the gather figures.
+        # A watchdog keeps the primary result if the collective stalls: the line is printed with the error and the process
+        # exits NON-ZERO, so a stuck multi-GPU run cannot be recorded as ok.
         import threading
 
         def give_up():
             if rank == 0:
                 out["with_gather"] = {"value": None, "error": f"gather did not finish within {args.gather_timeout} s"}
+                out["exit_code"] = 3
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(args.gather_timeout, give_up)
         dog.daemon = True
         dog.start()
         try:
-            run_gather(min(W, 5))
+            run_gather(min(max(W, 2), 8))
             sync()
-            t1 = time.perf_counter()
-            run_gather(K)
-            sync()
-            e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-            dist.all_reduce(e2, op=dist.ReduceOp.MAX)
-            e2 = float(e2.item())
+            greps = []
+            for r in range(max(1, args.repeats)):
+                sync()
+                t1 = time.perf_counter()
+                run_gather(K)
+                sync()
+                e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+                dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+                greps.append(float(e2.item()))
+            e2 = sorted(greps)[len(greps) // 2]
             ingest = (world - 1) * gather[0].msg_bytes * K / e2 / 1e9     # bytes that cross xGMI into the root
+            peak = (world - 1) * XGMI_LINK_GBS
             wg = {"value": world * n * K / e2, "unit": "env-steps/s", "ms_per_step": e2 / K * 1e3, "mode": args.gather,
-                  "bytes_per_step_at_root": gather[0].bytes_per_step(), "root_ingest_GBps": ingest,
-                  "root_ingest_peak_GBps": (world - 1) * XGMI_LINK_GBS, "overlapped_with_next_step": True,
-                  "zero_copy_message": True}
+                  "ms_per_step_repeats": [g / K * 1e3 for g in greps],
+                  "bytes_per_step_at_root": gather[0].bytes_per_step(),
+                  "roofline": {"bound": "xgmi-ingest", "achieved": ingest, "peak": peak, "unit": "GB/s", "frac": ingest / peak,
+                               "note": "bytes entering the root GPU per second against (N-1) links x 76.8 GB/s per direction"},
+                  "overlapped_with_next_step": True, "zero_copy_message": True}
         except Exception as e:  # noqa: BLE001
             wg = {"value": None, "error": repr(e)}
         dog.cancel()
         if rank == 0:
             out["with_gather"] = wg
+            out["scaling_claim"] = ("`value` (no collective in the step: the >= 6x at 8 GPUs of the north star refers to THIS figure) and "
+                                    "`with_gather.value` (BASELINE configs[4]: every step's obs/reward/done gathered to rank 0; bounded by the "
+                                    "root's xGMI ingress near 1.3e10 env-steps/s at any N, DESIGN.md 6) are both whole-job rates")
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not wl.get("loop") and wl["model"] != "auv_cyl":

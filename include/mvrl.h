@@ -16,8 +16,9 @@
  *     literally (NULL is HIP's null stream - what torch's default stream is), and return
  *     after enqueue; an event recorded behind each such enqueue orders any later
  *     host-pointer call (which runs on the handle's internal stream) after it, so e.g.
- *     mvrl_get_state after mvrl_step_dev needs no explicit synchronisation; a caller that
- *     switches between several of its own streams orders them itself;
+ *     mvrl_get_state after mvrl_step_dev needs no explicit synchronisation (one such event per
+ *     caller stream, all joined); work the caller spreads over several of its own streams is
+ *     ordered among those streams by the caller;
  *   - actions / observations are row-major [n_envs, dim] float32 at the ABI (what the
  *     reference's Gym API and SB3's VecEnv exchange); internal state is SoA in HBM;
  *   - the library owns all device buffers; it never retains a caller pointer past a call.
@@ -216,6 +217,15 @@ int mvrl_step_wait(mvrl_handle* h, float* obs, float* reward, uint8_t* done);
 int mvrl_step_f64(mvrl_handle* h, const double* actions, double* obs, double* reward, uint8_t* done);
 int mvrl_step_dev(mvrl_handle* h, const void* actions_dev, void* obs_dev, void* reward_dev, uint8_t* done_dev,
                   void* stream);
+
+/* The same step for the lanes [first_env, first_env + n_range) only (first_env a multiple of 64).  Environments are
+ * independent, so a caller may run sub-batches as separate CHAINS, each on its own stream - e.g. two half-batches whose
+ * policy/step sequences overlap (policy(A) while step(B)), which also hides the gap between dependent launches and the
+ * ramp/tail of every launch behind the other chain's kernel.  Pointers are the bases of the FULL [n_envs, dim] arrays
+ * (rows outside the range are not touched).  Replaces stepping a subset of SubprocVecEnv's workers
+ * (SB3 VecEnv.step_async on `indices`; the reference steps all of them, tag/main_00_sbl.py:145). */
+int mvrl_step_range_dev(mvrl_handle* h, int64_t first_env, int64_t n_range, const void* actions_dev, void* obs_dev,
+                        void* reward_dev, uint8_t* done_dev, void* stream);
 
 /* Observation of the step on which an env finished (SB3 infos[i]["terminal_observation"]); rows of envs
  * that did not finish on the last step are unspecified.  Only meaningful with auto_reset = 1. */

@@ -22,7 +22,7 @@ ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "EHIP", -5: "ESTATE"}
 SYMBOLS = [
     "mvrl_abi_version", "mvrl_device_count", "mvrl_last_error", "mvrl_model_dims", "mvrl_aux_dim", "mvrl_variant",
     "mvrl_create", "mvrl_destroy", "mvrl_set_flow", "mvrl_set_flow_dev", "mvrl_reset", "mvrl_reset_dev", "mvrl_step",
-    "mvrl_step_async", "mvrl_step_wait", "mvrl_step_dev", "mvrl_get_terminal_obs", "mvrl_get_terminal_obs_dev",
+    "mvrl_step_async", "mvrl_step_wait", "mvrl_step_dev", "mvrl_step_range_dev", "mvrl_get_terminal_obs", "mvrl_get_terminal_obs_dev",
     "mvrl_get_state", "mvrl_set_state", "mvrl_enable_aux", "mvrl_get_aux", "mvrl_flow_interp", "mvrl_flow_reconstruct",
     "mvrl_fill_uniform_dev", "mvrl_timing_begin", "mvrl_timing_end", "mvrl_dev_alloc", "mvrl_dev_free",
     "mvrl_dev_upload", "mvrl_dev_download", "mvrl_synchronize",
@@ -75,6 +75,7 @@ def load(path=None):
     lib.mvrl_step_async.argtypes = [vp, vp]
     lib.mvrl_step_wait.argtypes = [vp, vp, vp, vp]
     lib.mvrl_step_dev.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.mvrl_step_range_dev.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp]
     lib.mvrl_get_terminal_obs.argtypes = [vp, vp]
     lib.mvrl_get_terminal_obs_dev.argtypes = [vp, vp, vp]
     lib.mvrl_get_state.argtypes = [vp, vp, C.c_size_t]
@@ -284,6 +285,10 @@ class Handle:
     # -- device-pointer API (ints = raw device addresses, e.g. torch.Tensor.data_ptr()) -------------
     def step_dev(self, actions_ptr, obs_ptr, reward_ptr, done_ptr, stream=None):
         check(self.lib.mvrl_step_dev(self.h, actions_ptr, obs_ptr, reward_ptr, done_ptr, stream), self.h)
+
+    def step_range_dev(self, first, count, actions_ptr, obs_ptr, reward_ptr, done_ptr, stream=None):
+        """Step lanes [first, first + count) only; pointers are the bases of the full-batch arrays."""
+        check(self.lib.mvrl_step_range_dev(self.h, int(first), int(count), actions_ptr, obs_ptr, reward_ptr, done_ptr, stream), self.h)
 
     def rollout_dev(self, actions_ptr, obs_ptr, reward_ptr, done_ptr, k_steps, stream=None):
         check(self.lib.mvrl_rollout_dev(self.h, actions_ptr, obs_ptr, reward_ptr, done_ptr, int(k_steps), stream), self.h)

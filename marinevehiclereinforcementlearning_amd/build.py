@@ -35,6 +35,24 @@ def _gen_baked():
     return gen_f64.main()
 
 
+def source_hash():
+    """Identity of the kernels a profile was taken from: sha256 over the hand-written kernel sources, the generators of the
+    derived ones and the compiler flags.  Counter summaries under profiles/ carry it; bench.py drops them when it differs."""
+    import hashlib
+    hsh = hashlib.sha256()
+    names = [s_ for s_ in SOURCES if not s_.startswith("gen/")] + [h_ for h_ in HEADERS if not h_.startswith("gen/") and h_ != "mvrl_baked.inc"]
+    for name in sorted(names):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            hsh.update(name.encode() + b"\0" + f.read())
+    for tool in ("gen_baked.py", "gen_f64.py"):
+        with open(os.path.join(REPO, "tools", tool), "rb") as f:
+            hsh.update(f.read())
+    with open(os.path.join(HERE, "params.py"), "rb") as f:
+        hsh.update(f.read())
+    hsh.update(" ".join(fl for fl in FLAGS if not fl.startswith("/") and fl != "-I").encode())
+    return hsh.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

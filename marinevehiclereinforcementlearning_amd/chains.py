@@ -1,0 +1,79 @@
+"""Independent chains of sub-batches: software pipelining of one MarineVecEnv over several HIP streams.
+
+The environments of a batch never interact, so nothing orders lane i's step k+1 behind lane j's step k.  The reference
+gets that for free - every `SubprocVecEnv` worker steps on its own (tag_00_Dec2023_simpleControlTurbulence/main_00_sbl.py:145);
+a single fused launch per step gives it up again: launch k+1 waits for the LAST wave of launch k (the ramp and tail of
+every launch, plus the few microseconds between two dependent launches, leave a tenth of the chip idle).
+
+`ChainStepper` splits the batch into `n_chains` contiguous lane ranges and steps each range on its own stream through
+`mvrl_step_range_dev`: chain A's launch k+1 only waits for chain A's launch k, and while it drains and the next one
+ramps up, chain B's kernel keeps the SIMDs busy.  With a policy in the loop the same structure overlaps policy(A) with
+step(B).  Results are bit-identical to whole-batch steps (a lane's arithmetic does not depend on the launch geometry).
+
+    stepper = ChainStepper(env, n_chains=2)
+    stepper.fork()                        # chains start behind the work already queued on the current stream
+    for k in range(K):
+        stepper.step(actions[k])          # chain c: lanes [lo_c, hi_c) on stream c; returns the full-batch output tensors
+    stepper.join()                        # the current stream waits for every chain
+"""
+import torch
+
+
+class ChainStepper:
+    def __init__(self, env, n_chains=2, stagger=True, streams=None):
+        self.env = env
+        n = env.num_envs
+        n_chains = max(1, min(int(n_chains), (n + 63) // 64))
+        # contiguous ranges whose starts are multiples of 64 lanes (whole waves)
+        waves = (n + 63) // 64
+        cuts = [min(n, 64 * ((waves * c) // n_chains)) for c in range(n_chains)] + [n]
+        self.ranges = [(cuts[c], cuts[c + 1] - cuts[c]) for c in range(n_chains) if cuts[c + 1] > cuts[c]]
+        self.n_chains = len(self.ranges)
+        dev = torch.device("cuda", env.cfg.device)
+        self.streams = streams or [torch.cuda.Stream(device=dev) for _ in range(self.n_chains)]
+        self.stagger = bool(stagger) and self.n_chains > 1
+        self._armed = False
+        self._ev = [torch.cuda.Event() for _ in range(self.n_chains)]
+
+    def fork(self):
+        """Every chain waits for what is queued on the current stream (actions written there, a reset, ...).  The first step
+        after a fork is staggered: chain c starts when chain 0 has finished the first c/n_chains of its lanes, so that the
+        chains' launches end at different times from then on (kernels that start together end together, and their tails
+        and launch gaps would coincide again)."""
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            s.wait_stream(cur)
+        self._armed = self.stagger
+
+    def step(self, actions, out=None):
+        env = self.env
+        rt = torch.float64 if env.handle.f64 else torch.float32
+        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == rt
+        assert tuple(actions.shape) == (env.num_envs, env.action_space.shape[0])
+        obs, rew, done = out if out is not None else env._ensure_tensors()
+        ptrs = (actions.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+        raw = [s.cuda_stream for s in self.streams]
+        launch = env.handle.step_range_dev           # enqueues on the given raw stream: no torch stream switch needed
+        if self._armed:
+            self._armed = False
+            lo0, cnt0 = self.ranges[0]
+            C = self.n_chains
+            w0 = (cnt0 + 63) // 64
+            cuts = [lo0 + min(cnt0, 64 * ((w0 * j) // C)) for j in range(C)] + [lo0 + cnt0]
+            for j in range(C):
+                if cuts[j + 1] > cuts[j]:
+                    launch(cuts[j], cuts[j + 1] - cuts[j], *ptrs, raw[0])
+                if j < C - 1:
+                    self._ev[j].record(self.streams[0])
+            for c in range(1, C):
+                self.streams[c].wait_event(self._ev[c - 1])
+                launch(self.ranges[c][0], self.ranges[c][1], *ptrs, raw[c])
+            return obs, rew, done
+        for c, (lo, cnt) in enumerate(self.ranges):
+            launch(lo, cnt, *ptrs, raw[c])
+        return obs, rew, done
+
+    def join(self):
+        cur = torch.cuda.current_stream()
+        for s in self.streams:
+            cur.wait_stream(s)

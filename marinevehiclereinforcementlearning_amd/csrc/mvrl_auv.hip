@@ -178,8 +178,8 @@ __device__ __forceinline__ void auv_step_core(const AuvDev& p, const FlowDev& fl
 
 template <bool FLOW>
 __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, const StepIO io, const FlowDev fl) {
-    const uint32_t i = blockIdx.x * MVRL_BLOCK + threadIdx.x;
-    if (i >= (uint32_t)io.n) return;
+    const uint32_t i = (uint32_t)io.lane0 + blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= (uint32_t)io.lane_end) return;
     const uint32_t n32 = (uint32_t)io.n;
     char* const stb = reinterpret_cast<char*>(io.state);
 #define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) * (uint32_t)sizeof(float))))
@@ -235,9 +235,9 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
         // can be partial, and it takes the scattered path.
         __shared__ float tile[(MVRL_BLOCK / 64) * 64 * 11];
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        const uint32_t wave_base = (blockIdx.x * MVRL_BLOCK + wave * 64u);
+        const uint32_t wave_base = (uint32_t)io.lane0 + (blockIdx.x * MVRL_BLOCK + wave * 64u);
         float* t = tile + wave * 704u;
-        if (wave_base + 64u <= (uint32_t)io.n) {
+        if (wave_base + 64u <= (uint32_t)io.lane_end) {
 #pragma unroll
             for (int q = 0; q < 11; q++) t[lane * 11u + q] = o[q];
             __builtin_amdgcn_wave_barrier();
@@ -379,8 +379,8 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_reset_kernel(const AuvDev p, f
 // k_steps single-step launches to fp32 rounding, not bit for bit (the rigid-body kernels, one template for both, are).
 template <bool FLOW>
 __global__ __launch_bounds__(MVRL_BLOCK) void auv_rollout_kernel(const AuvDev p, const StepIO io, const FlowDev fl) {
-    const uint32_t i = blockIdx.x * MVRL_BLOCK + threadIdx.x;
-    if (i >= (uint32_t)io.n) return;
+    const uint32_t i = (uint32_t)io.lane0 + blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= (uint32_t)io.lane_end) return;
     const uint32_t n32 = (uint32_t)io.n;
     char* const stb = reinterpret_cast<char*>(io.state);
 #define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) * (uint32_t)sizeof(float))))
@@ -431,13 +431,14 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_rollout_kernel(const AuvDev p,
 }
 
 hipError_t launch_auv_step(const AuvDev& p, const StepIO& io, const FlowDev& fl, bool flow, hipStream_t stream) {
-    dim3 grid_r((unsigned)((io.n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block_r(MVRL_BLOCK);
+    const int64_t lanes = io.lane_end - io.lane0;
+    dim3 grid_r((unsigned)((lanes + MVRL_BLOCK - 1) / MVRL_BLOCK)), block_r(MVRL_BLOCK);
     if (io.k_steps > 1) {
         if (flow) hipLaunchKernelGGL((auv_rollout_kernel<true>), grid_r, block_r, 0, stream, p, io, fl);
         else hipLaunchKernelGGL((auv_rollout_kernel<false>), grid_r, block_r, 0, stream, p, io, fl);
         return hipGetLastError();
     }
-    dim3 grid((unsigned)((io.n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    dim3 grid((unsigned)((lanes + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
     if (flow) hipLaunchKernelGGL((auv_step_kernel<true>), grid, block, 0, stream, p, io, fl);
     else hipLaunchKernelGGL((auv_step_kernel<false>), grid, block, 0, stream, p, io, fl);
     return hipGetLastError();

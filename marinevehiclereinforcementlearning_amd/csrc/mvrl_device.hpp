@@ -294,6 +294,9 @@ struct StepIO {
     int auto_reset;
     float dt;
     int k_steps;            // > 1: fused multi-step launch (actions / obs / reward / done are [k_steps][n][...])
+    // lanes [lane0, lane_end) of the n-lane batch are stepped by this launch (mvrl_step_range_dev: independent chains of
+    // sub-batches on their own streams); every array is still indexed by the lane's position in the whole batch
+    int64_t lane0, lane_end;
 };
 
 }  // namespace mvrl

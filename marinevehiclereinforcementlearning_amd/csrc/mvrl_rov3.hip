@@ -178,8 +178,8 @@ struct Rhs3 {
 template <class PP, bool ZOH, bool FLOW, int INTEG, bool MULTI = false>
 __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
-    const uint32_t i_in = blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
-    if (i_in >= (uint32_t)io.n) return;
+    const uint32_t i_in = (uint32_t)io.lane0 + blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
+    if (i_in >= (uint32_t)io.lane_end) return;
     const uint32_t n32 = (uint32_t)io.n;  // see mvrl_rov6.hip: 32-bit byte offsets -> saddr addressing
     char* const stb = reinterpret_cast<char*>(io.state);
 #define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) * (uint32_t)sizeof(float))))
@@ -423,7 +423,7 @@ hipError_t launch_rov3_derivs(const Rov3Dev* p, bool baked, int64_t n, const flo
 
 hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool zoh, bool flow,
                             bool rk45, hipStream_t stream) {
-    dim3 grid((unsigned)((io.n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
+    dim3 grid((unsigned)((io.lane_end - io.lane0 + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
 #define MVRL_L3(PPT, Z, F) hipLaunchKernelGGL((rov3_step_kernel<PPT, Z, F, 0>), grid, block, 0, stream, p, io, fl)
 #if MVRL_F64
     if (rk45) {

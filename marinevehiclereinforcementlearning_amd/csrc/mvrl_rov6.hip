@@ -266,6 +266,34 @@ __device__ __forceinline__ Trig6 trig6(const float* y) {
     return t;
 }
 
+// sin/cos of the attitude at an RK stage whose angles differ from the sub-step's base angles by the small, known
+// increments d[3..5] (= c * k of the previous stage): rotate the base values by (cos d, sin d) from the [-pi/4, pi/4]
+// polynomials of sincos_f32 - no range reduction, no quadrant selection: 14 instructions per angle instead of ~35, three
+// of the four stages of every sub-step.  |d| <= pi/4 is checked per wave (the vehicle turns at < 5 rad/s, d = h * rate
+// ~ 0.1); a wave with a larger increment, and the fp64 build (whose parity bar is 1e-9), evaluate the stage in full.
+__device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, const float* d) {
+#if MVRL_F64 || defined(MVRL_FULL_STAGE_TRIG)
+    return trig6(yt);
+#else
+    const float m = fmaxf(fmaxf(fabsf(d[3]), fabsf(d[4])), fabsf(d[5]));
+    if (__builtin_expect(__any(m > 0.78f), 0)) return trig6(yt);
+    Trig6 t;
+    float sd[3], cd[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float r = d[3 + k], r2 = r * r;
+        const float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+        sd[k] = fmaf(ps * r2, r, r);
+        const float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+        cd[k] = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    }
+    t.sph = fmaf(b.cph, sd[0], b.sph * cd[0]); t.cph = fmaf(-b.sph, sd[0], b.cph * cd[0]);
+    t.sth = fmaf(b.cth, sd[1], b.sth * cd[1]); t.cth = fmaf(-b.sth, sd[1], b.cth * cd[1]);
+    t.sps = fmaf(b.cps, sd[2], b.sps * cd[2]); t.cps = fmaf(-b.sps, sd[2], b.cps * cd[2]);
+    return t;
+#endif
+}
+
 // One RHS evaluation in FAITHFUL mode = BlueROV2Heavy6DoF.derivs (6DoF.py:406-442), PID state mutated.
 // timeHistory columns F0..F5 (controller output) and u0..u7 (rpm) of the LAST derivs call of a step (6DoF.py:578-587)
 template <class PP>
@@ -277,9 +305,8 @@ __device__ __forceinline__ void write_aux6(PP p, const float* u, const float* cv
 }
 
 template <bool SYM, bool FLOW, bool HAS_DT, bool USE_INC, class PP>
-__device__ __forceinline__ void derivs6(PP p, const float* y, const float* sp, Pid6& pid, float dtp, float inv_den,
+__device__ __forceinline__ void derivs6(PP p, const float* y, const Trig6& t, const float* sp, Pid6& pid, float dtp, float inv_den,
                                         const float* dpose, bool inc_valid, float2 cur, float* dy, float* aux_row) {
-    Trig6 t = trig6(y);
     Axes ax = body_axes(t);
     float u[6], F[8], cv[8];
     pid6<HAS_DT, USE_INC>(p, y, sp, pid, dtp, inv_den, dpose, inc_valid, u);
@@ -289,8 +316,7 @@ __device__ __forceinline__ void derivs6(PP p, const float* y, const float* sp, P
 }
 
 template <bool SYM, bool FLOW, class PP>
-__device__ __forceinline__ void dynamics_only6(PP p, const float* y, const float* F, float2 cur, float* dy) {
-    Trig6 t = trig6(y);
+__device__ __forceinline__ void dynamics_only6(PP p, const float* y, const Trig6& t, const float* F, float2 cur, float* dy) {
     Axes ax = body_axes(t);
     dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, dy);
 }
@@ -392,8 +418,8 @@ __device__ unsigned long long g_stamp[5 * MVRL_STAMP_WAVES];
 template <class PP, bool SYM, bool ZOH, bool FLOW, int INTEG, bool MULTI = false>
 __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
-    const uint32_t i_in = blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
-    if (i_in >= (uint32_t)io.n) return;
+    const uint32_t i_in = (uint32_t)io.lane0 + blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
+    if (i_in >= (uint32_t)io.lane_end) return;
     const int k_steps = MULTI ? io.k_steps : 1;
     // the env's state: loaded before the first step of a launch and stored after the last one - in a fused launch it
     // stays in registers in between
@@ -498,15 +524,22 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
             allocate6<SYM>(p, ax, u, F, cvz);
             if (aux_last) write_aux6(p, u, cvz, aux_last);
             dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, k);
+            float dz[6];
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
-            dynamics_only6<SYM, FLOW>(p, yt, F, cur, k);
+#pragma unroll
+            for (int q = 3; q < 6; q++) dz[q] = hh * k[q];
+            dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
-            dynamics_only6<SYM, FLOW>(p, yt, F, cur, k);
+#pragma unroll
+            for (int q = 3; q < 6; q++) dz[q] = hh * k[q];
+            dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
-            dynamics_only6<SYM, FLOW>(p, yt, F, cur, k);
+#pragma unroll
+            for (int q = 3; q < 6; q++) dz[q] = h * k[q];
+            dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
 #pragma unroll
             for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (acc[q] + k[q]);  // pose change over this sub-step
         } else {
@@ -515,24 +548,25 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
             float dp[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) dp[q] = inc_prev[q];
-            derivs6<SYM, FLOW, false, true>(p, y, sp, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr);
+            const Trig6 tb = trig6(y);  // the sub-step's base attitude: the three later stages rotate it (stage_trig)
+            derivs6<SYM, FLOW, false, true>(p, y, tb, sp, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr);
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
 #pragma unroll
             for (int q = 0; q < 6; q++) dp[q] = hh * k[q];                       // (y + hh k1) - y
-            derivs6<SYM, FLOW, true, true>(p, yt, sp, pid, hh, inv_hh, dp, true, cur, k, nullptr);
+            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, dp), sp, pid, hh, inv_hh, dp, true, cur, k, nullptr);
             float d2[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }  // hh (k2 - k1)
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
-            derivs6<SYM, FLOW, false, true>(p, yt, sp, pid, 0.f, 1e9f, dp, true, cur, k, nullptr);
+            derivs6<SYM, FLOW, false, true>(p, yt, stage_trig(tb, yt, d2), sp, pid, 0.f, 1e9f, dp, true, cur, k, nullptr);
             float d3[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }          // h k3 - hh k2
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
-            derivs6<SYM, FLOW, true, true>(p, yt, sp, pid, hh, inv_hh, dp, true, cur, k, aux_last);
+            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, d3), sp, pid, hh, inv_hh, dp, true, cur, k, aux_last);
 #pragma unroll
             for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (acc[q] + k[q]) - d3[q];            // y_new - (y + h k3)
         }
@@ -701,7 +735,7 @@ hipError_t launch_rov6_derivs(const Rov6Dev* p, bool baked, bool sym, int64_t n,
 
 hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool sym, bool zoh,
                             bool flow, bool rk45, hipStream_t stream) {
-    dim3 grid((unsigned)((io.n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
+    dim3 grid((unsigned)((io.lane_end - io.lane0 + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
 #define MVRL_L6(S, Z, F) hipLaunchKernelGGL((rov6_step_kernel<CP6, S, Z, F, 0>), grid, block, 0, stream, p, io, fl)
 #define MVRL_L6B(Z, F) hipLaunchKernelGGL((rov6_step_kernel<const Rov6Baked*, true, Z, F, 0>), grid, block, 0, stream, p, io, fl)
 #if MVRL_F64

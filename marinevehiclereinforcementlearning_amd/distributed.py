@@ -134,6 +134,80 @@ class OutputGather:
         return self.unpack()
 
 
+class GatherPipeline:
+    """Step k+1 overlapped with the gather of step k: two message buffers, the exchange on a side stream.
+
+        pipe = GatherPipeline([OutputGather(...), OutputGather(...)], side_stream)
+        for k in range(K):
+            pipe.step(lambda out: env.step_tensors(actions[k], out=out))   # kernel writes message k & 1 in place
+        pipe.drain()
+
+    Ordering (events, no host synchronisation): the producer of step k may only overwrite buffer k & 1 once the exchange
+    of step k-2 - the previous user of that buffer - has finished (`ev_gather[b]`); the exchange of step k starts once
+    the producer has finished (`ev_step[b]`).  Both events of a buffer are re-recorded every second step; a wait only
+    ever refers to the most recent record, which is the one it needs.  `streams=None` runs the same logic with CPU
+    tensors (tests): the callbacks then run in program order and `log` records it."""
+
+    def __init__(self, gathers, side_stream=None, log=None):
+        assert len(gathers) == 2
+        self.g, self.side, self.k, self.log = gathers, side_stream, 0, log
+        self.cuda = side_stream is not None
+        if self.cuda:
+            self.ev_step = [torch.cuda.Event() for _ in range(2)]
+            self.ev_gather = [torch.cuda.Event() for _ in range(2)]
+
+    def step(self, produce):
+        """produce(out_views) enqueues the env step that writes this step's message.  Returns the buffer index used."""
+        b = self.k & 1
+        if self.cuda:
+            main = torch.cuda.current_stream()
+            if self.k >= 2:
+                main.wait_event(self.ev_gather[b])         # buffer b is free once gather k-2 has finished
+            produce(self.g[b].out_views())
+            self.ev_step[b].record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_step[b])
+                self.g[b].exchange()
+                self.ev_gather[b].record(self.side)
+        else:
+            if self.log is not None:
+                self.log.append(("produce", self.k, b))
+            produce(self.g[b].out_views())
+            if self.log is not None:
+                self.log.append(("exchange", self.k, b))
+            self.g[b].exchange()
+        self.k += 1
+        return b
+
+    def latest(self):
+        """The OutputGather holding the most recent step's message (valid after drain(), or on the side stream)."""
+        return self.g[(self.k - 1) & 1]
+
+    def drain(self):
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+def rccl_info(backend, local_rank):
+    """What a SCALE record needs to be audited: the backend that actually ran, how many ranks took part and whether they sat
+    on distinct devices (gathered over the group: each rank reports its device's PCI bus id)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    ident = None
+    try:
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = f"{getattr(props, 'pci_bus_id', '')}:{getattr(props, 'pci_device_id', '')}:{getattr(props, 'uuid', local_rank)}"
+    except Exception:  # noqa: BLE001
+        ident = f"cuda:{local_rank}"
+    idents = [None] * world
+    if dist.is_initialized():
+        dist.all_gather_object(idents, ident)
+    else:
+        idents = [ident]
+    return {"backend": (dist.get_backend() if dist.is_initialized() else None) or backend, "world_size_seen": world,
+            "ranks_on_distinct_devices": len(set(idents)) == world, "devices": idents,
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") and torch.cuda.is_available() else None}
+
+
 class ActionScatter:
     """The mirror of OutputGather: a consumer that lives on one rank - SB3's single process - holds the
     action batch for ALL envs; every step rank `root` scatters the shards, one message per rank, padded to the largest

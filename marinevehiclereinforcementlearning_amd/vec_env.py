@@ -217,6 +217,19 @@ class MarineVecEnv:
                             torch.cuda.current_stream().cuda_stream)
         return obs, rew, done
 
+    def step_range_tensors(self, first, count, actions, out=None):
+        """Step only the lanes [first, first + count) (first a multiple of 64) on torch's current stream.  `actions` and the
+        returned / `out` tensors are the FULL-batch tensors; rows outside the range are left alone.  Sub-batches stepped on
+        different streams form independent chains (see `chains.ChainStepper`)."""
+        import torch
+        rt = torch.float64 if self._h.f64 else torch.float32
+        assert actions.is_cuda and actions.is_contiguous() and actions.dtype == rt
+        assert tuple(actions.shape) == (self.num_envs, self.action_space.shape[0])
+        obs, rew, done = out if out is not None else self._ensure_tensors()
+        self._h.step_range_dev(first, count, actions.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+        return obs, rew, done
+
     def step_tensors(self, actions, out=None):
         """Device-resident step: `actions` is a contiguous float32 CUDA(HIP) tensor [N, act_dim]; returns
         (obs, reward, done_bits) tensors that are overwritten by the next call.  Enqueued on torch's current stream;

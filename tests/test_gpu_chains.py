@@ -1,0 +1,88 @@
+"""Lane-range stepping (mvrl_step_range_dev) and the chain stepper built on it: a batch stepped as independent chains of
+sub-batches on their own streams must end in EXACTLY the state, observations, rewards and dones of whole-batch steps -
+random auto-resets included (a lane's arithmetic and its Philox stream do not depend on the launch geometry)."""
+import numpy as np
+import pytest
+
+from marinevehiclereinforcementlearning_amd import _lib, params as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _flow():
+    from marinevehiclereinforcementlearning_amd.flow import ReconstructedFlow
+    f = ReconstructedFlow.synthetic(n_modes=4, n_time=64)
+    f.scale(11., 1., 2., translate=(-1.65, -1.1))
+    return f
+
+
+@pytest.mark.parametrize("model,n,chains", [("rov6", 8192 + 77, 2), ("rov6", 4096, 3), ("rov3", 5000, 2), ("auv", 6000, 2),
+                                            ("auv_cyl", 3000, 4)])
+def test_chains_bit_identical_to_whole_batch_steps(model, n, chains):
+    import torch
+    from marinevehiclereinforcementlearning_amd.chains import ChainStepper
+    from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
+    steps, max_steps = 23, 9   # several random auto-resets inside the run
+    kw = dict(seed=11, maxSteps=max_steps, infos="lean")
+    flow_a, flow_b = _flow(), _flow()
+    ea = MarineVecEnv(model, n, flow=flow_a, **kw)
+    eb = MarineVecEnv(model, n, flow=flow_b, **kw)
+    act_dim = ea.action_space.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    acts = torch.rand((steps, n, act_dim), device="cuda", generator=g) * 2 - 1
+    oa0 = ea.reset_tensors().clone()
+    ob0 = eb.reset_tensors().clone()
+    assert torch.equal(oa0, ob0)
+    st = ChainStepper(eb, n_chains=chains)
+    assert st.n_chains == chains and sum(c for _, c in st.ranges) == n and all(lo % 64 == 0 for lo, _ in st.ranges)
+    outs_a, outs_b = [], []
+    for k in range(steps):
+        o, r, d = ea.step_tensors(acts[k])
+        outs_a.append((o.clone(), r.clone(), d.clone()))
+    st.fork()
+    bufs = [tuple(torch.empty_like(t) for t in outs_a[0]) for _ in range(steps)]
+    for k in range(steps):
+        st.step(acts[k], out=bufs[k])   # own output tensors per step: chains run ahead of each other
+    st.join()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        for ta, tb in zip(outs_a[k], bufs[k]):
+            assert torch.equal(ta, tb), (model, k)
+    assert np.array_equal(ea.get_state(), eb.get_state())
+    assert np.array_equal(ea.handle.terminal_obs(), eb.handle.terminal_obs())
+    assert int(ea.handle.episode_counter().max()) >= 3     # resets really happened
+    ea.close(); eb.close()
+
+
+def test_range_arguments_are_checked():
+    h = _lib.Handle(P.make_config("rov6", 1000, auto_reset=False, max_steps=10))
+    a = h.dev_alloc(1000 * 6 * 4); o = h.dev_alloc(1000 * 9 * 4); r = h.dev_alloc(4000); d = h.dev_alloc(1000)
+    for first, cnt in [(-64, 64), (32, 64), (960, 64), (0, 0), (0, 1001)]:
+        with pytest.raises(_lib.MvrlError):
+            h.step_range_dev(first, cnt, a, o, r, d, None)
+    h.step_range_dev(960, 40, a, o, r, d, None)   # ragged tail range is fine
+    h.synchronize()
+    for p in (a, o, r, d):
+        h.dev_free(p)
+    h.close()
+
+
+def test_host_call_after_chains_waits_for_every_stream():
+    """get_state() (host-pointer entry point, the handle's own stream) after range launches on two caller streams must see
+    both: the handle keeps one join event per caller stream."""
+    import torch
+    from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
+    n = 262144
+    e = MarineVecEnv("rov6", n, seed=3, infos="lean")
+    e.reset_tensors()
+    acts = torch.rand((n, 6), device="cuda") * 2 - 1
+    obs, rew, done = e._ensure_tensors()
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ptr = (acts.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+    for _ in range(20):
+        e.handle.step_range_dev(0, n // 2, *ptr, s0.cuda_stream)
+        e.handle.step_range_dev(n // 2, n // 2, *ptr, s1.cuda_stream)
+    cnt = e.handle.step_counter()          # no explicit synchronisation
+    assert (cnt == 20).all()
+    e.close()

@@ -19,6 +19,7 @@ VARIANTS = {
     "blk256": dict(extra=["-DMVRL_STEP_BLOCK=256"], drop=()),
     "slp": dict(extra=[], drop=("-fno-slp-vectorize",)),
     "nofast": dict(extra=[], drop=("-ffast-math",)),
+    "fulltrig": dict(extra=["-DMVRL_FULL_STAGE_TRIG"], drop=()),      # full sincos at every RK stage (round-1 behaviour)
     "native": dict(extra=["-DMVRL_NATIVE_TRIG"], drop=()),            # hardware v_sin/v_cos (1e-6 absolute accuracy)
     "w2": dict(extra=["-DMVRL_MIN_WAVES=2"], drop=()),
     "w3": dict(extra=["-DMVRL_MIN_WAVES=3"], drop=()),
