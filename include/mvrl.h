@@ -209,8 +209,10 @@ int mvrl_reset_dev(mvrl_handle* h, const uint8_t* mask_dev, const void* init_dev
 /* ---- step: replaces Env.step (6DoF.py:531-594, 3DoF.py:455-514, verySimpleAuv.py:264-410) -------------
  * and SB3 VecEnv.step_async/step_wait (called at tag/main_00_sbl.py:145-161 through agent.learn).
  * actions [n_envs, act_dim] f32 ; obs [n_envs, obs_dim] f32 ; reward [n_envs] f32 ; done [n_envs] u8:
- * 0 = running, non-zero = done; bit 1 (value 2) is set when the episode ended on the time limit (SB3's
- * info["TimeLimit.truncated"]), clear when it ended on a bounds violation (AuvEnv, verySimpleAuv.py:335-342). */
+ * 0 = running, non-zero = done; bit 1 (value 2) is set when the episode ended on the time limit, clear when it
+ * ended on a bounds violation (AuvEnv, verySimpleAuv.py:335-342).  The reference's envs do not tell the two apart
+ * (info = {}); the bit is extra information a caller may surface as SB3's info["TimeLimit.truncated"]
+ * (MarineVecEnv(report_truncation=True)). */
 int mvrl_step(mvrl_handle* h, const float* actions, float* obs, float* reward, uint8_t* done);
 int mvrl_step_async(mvrl_handle* h, const float* actions);
 int mvrl_step_wait(mvrl_handle* h, float* obs, float* reward, uint8_t* done);
@@ -303,13 +305,16 @@ int mvrl_policy_predict_dev(mvrl_policy* p, const float* obs_dev, float* actions
 
 /* ---- learner-side consumer: CustomReplayBuffer.add with symmetry augmentation ----------------
  * tag/main_02_sbl_contrib_customBuffer.py:76-160.  All pointers are DEVICE pointers.  obs/next_obs [n_envs, 11],
- * actions [n_envs, 3], reward [n_envs] f32, done [n_envs] u8 as produced by mvrl_step_dev (bit 1 = time limit ->
- * the buffer's `timeouts`).  The ring buffers are [buffer_size, n_envs, dim].  Writes n_transforms (5, or 1 once the
+ * actions [n_envs, 3], reward [n_envs] f32, done [n_envs] u8 as produced by mvrl_step_dev.  record_timeouts = 0 writes
+ * `timeouts` = 0 - the reference's behaviour: its envs return info = {} (verySimpleAuv.py:410), so
+ * info.get("TimeLimit.truncated", False) at :154 is always False and a time-limit `done` is a true terminal;
+ * record_timeouts = 1 copies bit 1 of the done byte (time limit) into `timeouts` for learners that bootstrap through
+ * truncations.  The ring buffers are [buffer_size, n_envs, dim].  Writes n_transforms (5, or 1 once the
  * buffer has rolled over more than twice, :143) consecutive slots starting at `pos`; the caller advances pos. */
 int mvrl_replay_add_sym_dev(int32_t device, const float* obs, const float* next_obs, const float* actions, const float* reward,
                             const uint8_t* done, int64_t n_envs, float* buf_obs, float* buf_next_obs, float* buf_actions,
                             float* buf_reward, uint8_t* buf_done, uint8_t* buf_timeout, int64_t buffer_size, int64_t pos,
-                            int32_t n_transforms, void* stream);
+                            int32_t n_transforms, int32_t record_timeouts, void* stream);
 
 /* ---- benchmark helpers -------------------------------------------------------------------------------- */
 /* Whole episodes of the PD baseline in ONE launch - evaluate_agent(PDController(policy_dt, P, D), AuvEnv)

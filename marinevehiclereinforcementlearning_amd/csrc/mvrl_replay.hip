@@ -29,7 +29,9 @@ __global__ __launch_bounds__(MVRL_BLOCK) void replay_add_sym_kernel(const float*
 #pragma unroll
     for (int k = 0; k < 3; k++) a[k] = act[i * 3 + k];
     const float r = rew[i];
-    const uint8_t d = done[i] ? 1 : 0, to = (timeout[i] & 2) ? 1 : 0;   // done bytes carry the time-limit bit (include/mvrl.h)
+    // done bytes carry the time-limit bit (include/mvrl.h); timeout == nullptr: the reference's own pipeline, whose envs never
+    // report "TimeLimit.truncated" (verySimpleAuv.py:410 returns {}), so info.get(...) is False for every transition (:154)
+    const uint8_t d = done[i] ? 1 : 0, to = (timeout && (timeout[i] & 2)) ? 1 : 0;
     for (int t = 0; t < n_tr; t++) {
         int64_t slot = pos + t;
         if (slot >= buffer_size) slot -= buffer_size;                    // the ring wraps inside one add (:156-159)

@@ -402,13 +402,56 @@ struct Rhs6 {
 // Profiling build only (tools/stamp_probe.py): per-wave s_memtime stamps at the phase boundaries of the step kernel.
 #define MVRL_STAMP_WAVES 32768
 __device__ unsigned long long g_stamp[5 * MVRL_STAMP_WAVES];
+__device__ unsigned long long g_stamp_rt[5 * MVRL_STAMP_WAVES];   // s_memrealtime (100 MHz) twin: in-kernel shader clock
 #define STAMP(slot)                                                                                          \
     do {                                                                                                     \
         unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                \
-        if (threadIdx.x == 0 && blockIdx.x < MVRL_STAMP_WAVES) g_stamp[(slot) * MVRL_STAMP_WAVES + blockIdx.x] = t_; \
+        unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                                            \
+        if (threadIdx.x == 0 && blockIdx.x < MVRL_STAMP_WAVES) {                                             \
+            g_stamp[(slot) * MVRL_STAMP_WAVES + blockIdx.x] = t_;                                            \
+            g_stamp_rt[(slot) * MVRL_STAMP_WAVES + blockIdx.x] = r_;                                         \
+        }                                                                                                    \
     } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#endif
+
+// Register parking (fp32 FAITHFUL step kernels, MVRL_PARK): the sub-step's base state y[12] and the RK4 slope accumulator
+// acc[12] are needed only between the stages, not inside an RHS evaluation - they wait in LDS (a wave-private 6 KB
+// tile, 3 x 16 B per lane and array, conflict-free b128 accesses, no barrier: a lane only reads what it wrote) so that
+// the RHS has 24 more registers.  That takes the kernel from 156 to <= 128 VGPRs = FOUR resident waves per SIMD instead
+// of three; the SIMD's issue slots rotate over 1, 2, 4 or 8 wave slots, so a fourth wave is worth more than a third
+// (tools/valu_dep.hip).  33 LDS instructions per sub-step against ~1450 VALU.
+#if !MVRL_F64 && !defined(MVRL_NO_PARK)
+#define MVRL_PARK_ON 1
+#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, SYM ? 4 : 1)
+// LDS per block = 10 KB although the parked tiles need 6: 160 KB / 10 KB = 16 one-wave blocks per CU = exactly four waves
+// per SIMD.  A kernel instance that happens to need <= 96 VGPRs would otherwise get a FIFTH wave, and five waves rotate
+// over eight issue slots (tools/valu_dep.hip).
+#ifndef MVRL_PARK_FLOAT4S
+#define MVRL_PARK_FLOAT4S 640
+#endif
+struct Park12 {
+    volatile float4* base;   // [3][MVRL_STEP_BLOCK]
+    __device__ __forceinline__ void put(const float* v) const {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float4 t; t.x = v[4 * j]; t.y = v[4 * j + 1]; t.z = v[4 * j + 2]; t.w = v[4 * j + 3];
+            const_cast<float4&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]) = t;
+        }
+        asm volatile("" ::: "memory");   // no store-to-load forwarding across the parking: the value must leave its registers
+    }
+    __device__ __forceinline__ void get(float* v) const {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float4 t = const_cast<const float4&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]);
+            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        }
+    }
+};
+#else
+#define MVRL_STEP_BOUNDS6 MVRL_STEP_BOUNDS
 #endif
 
 // MULTI: io.k_steps consecutive env steps in ONE launch (mvrl_rollout_dev): the same body run k_steps times on
@@ -416,11 +459,16 @@ __device__ unsigned long long g_stamp[5 * MVRL_STAMP_WAVES];
 // synchronisation is needed between the steps; what the fused launch saves is the ~6 us between dependent launches, the
 // ramp and tail of every launch, and the HBM latency of the state loads (the lane's planes come back from L2).
 template <class PP, bool SYM, bool ZOH, bool FLOW, int INTEG, bool MULTI = false>
-__global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
+__global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
     const uint32_t i_in = (uint32_t)io.lane0 + blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
     if (i_in >= (uint32_t)io.lane_end) return;
     const int k_steps = MULTI ? io.k_steps : 1;
+#ifdef MVRL_PARK_ON
+    __shared__ float4 park_lds[MVRL_PARK_FLOAT4S];
+    static_assert(MVRL_PARK_FLOAT4S >= 2 * 3 * MVRL_STEP_BLOCK, "parking tile");
+    const Park12 park_y{park_lds}, park_a{park_lds + 3 * MVRL_STEP_BLOCK};
+#endif
     // the env's state: loaded before the first step of a launch and stored after the last one - in a fused launch it
     // stays in registers in between
     float y[12], sp[6], path[6];
@@ -525,6 +573,45 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
             if (aux_last) write_aux6(p, u, cvz, aux_last);
             dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, k);
             float dz[6];
+#ifdef MVRL_PARK_ON
+            {
+                float a[12], yb[12];
+                park_y.put(y);
+                park_a.put(k);
+#pragma unroll
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(hh, k[q], y[q]);
+#pragma unroll
+                for (int q = 3; q < 6; q++) dz[q] = hh * k[q];
+                dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
+                park_a.get(a);
+#pragma unroll
+                for (int q = 0; q < 12; q++) a[q] = fmaf(2.f, k[q], a[q]);
+                park_a.put(a);
+                park_y.get(yb);
+#pragma unroll
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(hh, k[q], yb[q]);
+#pragma unroll
+                for (int q = 3; q < 6; q++) dz[q] = hh * k[q];
+                dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
+                park_a.get(a);
+#pragma unroll
+                for (int q = 0; q < 12; q++) a[q] = fmaf(2.f, k[q], a[q]);
+                park_a.put(a);
+                park_y.get(yb);
+#pragma unroll
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(h, k[q], yb[q]);
+#pragma unroll
+                for (int q = 3; q < 6; q++) dz[q] = h * k[q];
+                dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
+                park_a.get(a);
+                park_y.get(yb);
+#pragma unroll
+                for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (a[q] + k[q]);
+#pragma unroll
+                for (int q = 0; q < 12; q++) y[q] = fmaf(h6, a[q] + k[q], yb[q]);
+                continue;
+            }
+#endif
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
 #pragma unroll
@@ -549,6 +636,47 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
 #pragma unroll
             for (int q = 0; q < 6; q++) dp[q] = inc_prev[q];
             const Trig6 tb = trig6(y);  // the sub-step's base attitude: the three later stages rotate it (stage_trig)
+#ifdef MVRL_PARK_ON
+            {
+                // same arithmetic, same order of operations as below; y and acc live in LDS between the stages
+                park_y.put(y);
+                derivs6<SYM, FLOW, false, true>(p, y, tb, sp, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr);
+                park_a.put(k);
+#pragma unroll
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(hh, k[q], y[q]);
+#pragma unroll
+                for (int q = 0; q < 6; q++) dp[q] = hh * k[q];
+                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, dp), sp, pid, hh, inv_hh, dp, true, cur, k, nullptr);
+                float d2[6], d3[6], a[12], yb[12];
+                park_a.get(a);
+#pragma unroll
+                for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - a[q]); d2[q] = hh * k[q]; }
+#pragma unroll
+                for (int q = 0; q < 12; q++) a[q] = fmaf(2.f, k[q], a[q]);
+                park_a.put(a);
+                park_y.get(yb);
+#pragma unroll
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(hh, k[q], yb[q]);
+                derivs6<SYM, FLOW, false, true>(p, yt, stage_trig(tb, yt, d2), sp, pid, 0.f, 1e9f, dp, true, cur, k, nullptr);
+#pragma unroll
+                for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
+                park_a.get(a);
+#pragma unroll
+                for (int q = 0; q < 12; q++) a[q] = fmaf(2.f, k[q], a[q]);
+                park_a.put(a);
+                park_y.get(yb);
+#pragma unroll
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(h, k[q], yb[q]);
+                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, d3), sp, pid, hh, inv_hh, dp, true, cur, k, aux_last);
+                park_a.get(a);
+                park_y.get(yb);
+#pragma unroll
+                for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (a[q] + k[q]) - d3[q];
+#pragma unroll
+                for (int q = 0; q < 12; q++) y[q] = fmaf(h6, a[q] + k[q], yb[q]);
+                continue;
+            }
+#endif
             derivs6<SYM, FLOW, false, true>(p, y, tb, sp, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr);
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
@@ -647,6 +775,9 @@ __global__ MVRL_STEP_BOUNDS void rov6_step_kernel(const Rov6Dev* __restrict__ pg
 #ifdef MVRL_STAMP_ON
 extern "C" int mvrl_debug_stamps(unsigned long long* dst, size_t n_words) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamp), n_words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int mvrl_debug_stamps_rt(unsigned long long* dst, size_t n_words) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamp_rt), n_words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
 }
 #endif
 

@@ -1,47 +1,64 @@
-"""Episode evaluation and time-history export around the environments - the callers on the other side of the boundary
+"""Episode roll-outs and time-history export around the environments - the callers on the other side of the boundary
 (SURVEY.md 8(f) rank 3):
 
-    evaluate_agent     tag_00_Dec2023_simpleControlTurbulence/resources.py:49-102 (same signature minus `render`):
-                       single-env loop obs -> agent.predict -> env.step, writes <saveDir>/ep_<k>.csv from env.timeHistory
+    run_episodes       drives ONE single-env Gym facade (envs.AuvEnv & co.) with an agent for whole episodes and, on
+                       request, writes each episode's `env.timeHistory` as <out_dir>/ep_<k>.csv - the on-disk format the
+                       reference's evaluation writes (tag_00_Dec2023_simpleControlTurbulence/resources.py:82-85) and its
+                       plotting scripts read.  The reference's own `evaluate_agent` (:49-102) drives `envs.AuvEnv`
+                       unchanged, since the facade keeps the Gym API; `run_episodes` is this package's loop, with scoring
+                       rules spelled out and per-episode lengths returned.  For batches use
+                       `policies.PDController.run_episodes(vec_env)` (one fused launch per batch of episodes).
     EpisodeRecorder    the same CSV schema (verySimpleAuv.py:389-403 / 6DoF.py:578-587 / 3DoF.py:498-507) for a few
                        tracked lanes of a MarineVecEnv - never per-lane at 1e6 envs
 """
 import os
+from collections import namedtuple
 
 import numpy as np
 
+EpisodeSummary = namedtuple("EpisodeSummary", "scores lengths mean median files")
 
-def evaluate_agent(agent, env, num_episodes=1, num_steps=None, deterministic=True, num_last_for_reward=None, init=None,
-                   saveDir=None, verbose=True):
-    keepHistory = False
-    if saveDir is not None:
-        os.makedirs(saveDir, exist_ok=True)
-        keepHistory = True
-    all_episode_rewards = []
-    for iEp in range(num_episodes):
-        episode_rewards = []
-        obs = env.reset(fixedInitialValues=init, keepTimeHistory=keepHistory)
-        if num_steps is None:
-            num_steps = 1000000
-        for i in range(num_steps):
-            action, _states = agent.predict(obs, deterministic=deterministic)
-            obs, reward, done, info = env.step(action)
-            episode_rewards.append(reward)
-            if done:
-                if saveDir is not None:
-                    env.timeHistory.to_csv(os.path.join(saveDir, "ep_{:d}.csv".format(iEp)), index=False)
-                break
-        if num_last_for_reward is None:
-            all_episode_rewards.append(sum(episode_rewards))
+
+def _roll_one(agent, env, reset_kwargs, step_cap, deterministic):
+    """One episode: yields (reward, done) after every env step until `done` or the cap."""
+    obs = env.reset(**reset_kwargs)
+    taken = 0
+    while step_cap is None or taken < step_cap:
+        action, _ = agent.predict(obs, deterministic=deterministic)
+        obs, reward, done, _info = env.step(action)
+        taken += 1
+        yield float(reward), bool(done)
+        if done:
+            return
+
+
+def run_episodes(agent, env, episodes=1, step_cap=None, init=None, out_dir=None, score="sum", deterministic=True):
+    """Roll `episodes` episodes of `agent` on the single-env facade `env`.
+
+    init     : fixedInitialValues handed to env.reset ([position(2), heading, headingTarget] for AuvEnv), or None
+    score    : "sum" - the episode return; ("mean_last", k) - mean reward of the last k steps of the episode
+    out_dir  : if given, env keeps its timeHistory and every FINISHED episode (done reached) is written to ep_<k>.csv
+    Returns EpisodeSummary(scores, lengths, mean, median, files)."""
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+    reset_kwargs = dict(fixedInitialValues=init, keepTimeHistory=out_dir is not None)
+    scores, lengths, files = [], [], []
+    for ep in range(int(episodes)):
+        rewards, finished = [], False
+        for reward, finished in _roll_one(agent, env, reset_kwargs, step_cap, deterministic):
+            rewards.append(reward)
+        if finished and out_dir is not None:
+            path = os.path.join(out_dir, f"ep_{ep:d}.csv")
+            env.timeHistory.to_csv(path, index=False)
+            files.append(path)
+        lengths.append(len(rewards))
+        if score == "sum":
+            scores.append(float(np.sum(rewards)))
         else:
-            all_episode_rewards.append(np.mean(episode_rewards[-num_last_for_reward:]))
-    mean_episode_reward = np.mean(all_episode_rewards)
-    median_episode_reward = np.median(all_episode_rewards)
-    if verbose:
-        print("  Mean reward:  ", mean_episode_reward)
-        print("  Median reward:", median_episode_reward)
-        print("  Num episodes: ", num_episodes)
-    return mean_episode_reward, median_episode_reward, all_episode_rewards
+            kind, k = score
+            assert kind == "mean_last"
+            scores.append(float(np.mean(rewards[-int(k):])))
+    return EpisodeSummary(scores, lengths, float(np.mean(scores)), float(np.median(scores)), files)
 
 
 AUV_COLUMNS = (["step", "time", "reward", "x", "y", "psi", "x_d", "y_d", "psi_d", "Fx", "Fy", "N", "Fx_set", "Fy_set",

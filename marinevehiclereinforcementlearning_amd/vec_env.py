@@ -11,9 +11,11 @@ of SB3 1.6-1.8 (gym 0.21 API, which is what the reference uses):
     step_async(actions) ; step_wait() -> (obs, rewards[N] f32, dones[N] bool, infos: list[dict])
     step(actions) ; close() ; seed() ; get_attr / set_attr / env_method / env_is_wrapped ; render()
 with SB3's auto-reset semantics: on a `done` the returned row of `obs` is the first observation of the next
-episode, the last observation of the finished one is in infos[i]["terminal_observation"], and
-infos[i]["TimeLimit.truncated"] tells whether the episode ended on the time limit
-(read at main_02_sbl_contrib_customBuffer.py:154).
+episode and the last observation of the finished one is in infos[i]["terminal_observation"].  The reference's envs are not
+TimeLimit-wrapped and return info = {} (verySimpleAuv.py:410), so `info.get("TimeLimit.truncated", False)` at
+main_02_sbl_contrib_customBuffer.py:154 is always False there: a time-limit `done` is a true terminal.  That is the
+default here too; `report_truncation=True` adds infos[i]["TimeLimit.truncated"] (from the done byte's time-limit bit) for
+learners that want to bootstrap through truncations - a deliberate, opt-in deviation.
 
 `infos="lean"` returns one shared, lazily-evaluated infos object instead of N dicts - at 1e5..1e7 environments the
 list of dicts alone costs more than the physics.  `step_tensors` keeps actions/observations on the GPU
@@ -28,8 +30,8 @@ from .spaces import unit_box
 class _LeanInfos:
     """Sequence-like infos for huge batches: infos[i] builds the dict on demand."""
 
-    def __init__(self, env, done_bits, term_obs_fetch):
-        self._env, self._bits, self._fetch = env, done_bits, term_obs_fetch
+    def __init__(self, env, done_bits, term_obs_fetch, report_truncation=False):
+        self._env, self._bits, self._fetch, self._trunc = env, done_bits, term_obs_fetch, report_truncation
         self._term = None
 
     def __len__(self):
@@ -41,7 +43,10 @@ class _LeanInfos:
             return {}
         if self._term is None:
             self._term = self._fetch()
-        return {"terminal_observation": self._term[i], "TimeLimit.truncated": bool(b & 2)}
+        info = {"terminal_observation": self._term[i]}
+        if self._trunc:
+            info["TimeLimit.truncated"] = bool(b & 2)
+        return info
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
@@ -65,7 +70,7 @@ class MarineVecEnv:
     def __init__(self, model, num_envs, *, seed=0, dt=None, maxSteps=250, n_substeps=4, control_mode="faithful",
                  fixed_setpoint=False, flow=None, currentVelScale=1.0, currentTurbScale=2.0, noiseMagCoeffs=0.0,
                  noiseMagActuation=0.0, stopOnBoundsExceeded=True, device=0, env_offset=0, infos="dict",
-                 vehicle_params=None, precision="f32", integrator="rk4"):
+                 vehicle_params=None, precision="f32", integrator="rk4", report_truncation=False):
         cyl = model == "auv_cyl"          # AuvEnvCyl: AuvEnv with way-points (tag/verySimpleAuv_cyl.py)
         if cyl:
             model = "auv"
@@ -77,6 +82,7 @@ class MarineVecEnv:
         self.action_space = unit_box(act)
         self.observation_space = unit_box(obs)
         self.infos_mode = infos
+        self.report_truncation = bool(report_truncation)
         cm = {"faithful": P.CTRL_FAITHFUL, "zoh": P.CTRL_ZOH}[control_mode] if isinstance(control_mode, str) else control_mode
         use_flow = flow is not None
         if self.model == P.MODEL_AUV and flow is None:
@@ -120,14 +126,16 @@ class MarineVecEnv:
         bits = done.copy()
         dones = bits != 0
         if self.infos_mode == "lean":
-            infos = _LeanInfos(self, bits, self._h.terminal_obs)
+            infos = _LeanInfos(self, bits, self._h.terminal_obs, self.report_truncation)
         else:
             infos = [{} for _ in range(self.num_envs)]
             idx = np.nonzero(dones)[0]
             if len(idx):
                 term = self._h.terminal_obs()
                 for i in idx:
-                    infos[i] = {"terminal_observation": term[i].copy(), "TimeLimit.truncated": bool(bits[i] & 2)}
+                    infos[i] = {"terminal_observation": term[i].copy()}
+                    if self.report_truncation:
+                        infos[i]["TimeLimit.truncated"] = bool(bits[i] & 2)
         return obs.copy(), rew.copy(), dones, infos
 
     def step(self, actions):

@@ -1,9 +1,10 @@
 """numpy restatement of CustomReplayBuffer.add (tag_00_Dec2023_simpleControlTurbulence/main_02_sbl_contrib_customBuffer.py:
 76-160).  TEST INFRASTRUCTURE ONLY.
 
-Parity UNPINNED by execution: the reference class derives from stable_baselines3.ReplayBuffer, which is not installed in
-the build container (no network), so it cannot be imported to generate fixtures.  The five +-1 masks and the slot
-bookkeeping below are transcribed from the source lines cited; the GPU kernel is checked against this restatement."""
+Pinned: tests/golden/g20_replay.npz was written by executing the reference class itself (oracle/gen/gen_golden_replay.py;
+stable_baselines3 is not installed, so the SB3 base-class constructor - array allocation only - is stubbed, `add` runs
+unmodified); tests/test_replay_cpu.py checks this restatement against it bit for bit, through the roll-over that falls in
+the middle of an add.  The GPU kernel is checked against the fixture and, on larger random batches, against this class."""
 import numpy as np
 
 T_OBS = np.array([[1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1], [-1, -1, 1, 1, -1, -1, -1, -1, 1, 1, 1], [-1, 1, 1, 1, -1, 1, -1, 1, 1, 1, 1],

@@ -21,7 +21,7 @@ flow.scale(11., 1., 2., translate=(-1.65, -1.1))
 env = MarineVecEnv("rov6", n, seed=1, flow=flow, infos="lean")
 env.reset_tensors()
 act = torch.rand((4, n, 6), device="cuda") * 2 - 1
-for k in range(12):
+for k in range(int(os.environ.get('WARM', 3000))):
     env.step_tensors(act[k % 4])
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -38,6 +38,15 @@ rc = lib.mvrl_debug_stamps(buf.ctypes.data, buf.size)
 assert rc == 0, rc
 nw = min(W, (n + 63) // 64)
 t = buf.reshape(5, W)[:, :nw].astype(np.int64)
+if hasattr(lib, "mvrl_debug_stamps_rt"):
+    rt = np.zeros(5 * W, np.uint64)
+    lib.mvrl_debug_stamps_rt.argtypes = [C.c_void_p, C.c_size_t]
+    assert lib.mvrl_debug_stamps_rt(rt.ctypes.data, rt.size) == 0
+    rt = rt.reshape(5, W)[:, :nw].astype(np.int64)
+    clk = (t[2] - t[1]) / np.maximum(1, rt[2] - rt[1]) * 100.0   # MHz: shader cycles per 10 ns tick of s_memrealtime
+    print(f"in-kernel shader clock over the RK4 loop (s_memtime / s_memrealtime): median {np.median(clk):.0f} MHz  p10 {np.percentile(clk, 10):.0f}  p90 {np.percentile(clk, 90):.0f}")
+    life = (rt[4] - rt[0]) * 10e-3
+    print(f"wave life in real time: median {np.median(life):.2f} us, loop {np.median((rt[2] - rt[1]) * 10e-3):.2f} us, load {np.median((rt[1] - rt[0]) * 10e-3):.2f} us")
 for k in range(5):
     print("slot", k, "zeros", int((t[k] == 0).sum()), "min", int(t[k].min()), "max", int(t[k].max()))
 # s_memtime counters of different XCDs are not aligned: cluster the waves by counter domain (gaps >> kernel length)

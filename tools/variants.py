@@ -21,10 +21,14 @@ VARIANTS = {
     "nofast": dict(extra=[], drop=("-ffast-math",)),
     "fulltrig": dict(extra=["-DMVRL_FULL_STAGE_TRIG"], drop=()),      # full sincos at every RK stage (round-1 behaviour)
     "native": dict(extra=["-DMVRL_NATIVE_TRIG"], drop=()),            # hardware v_sin/v_cos (1e-6 absolute accuracy)
+    "nopark": dict(extra=["-DMVRL_NO_PARK"], drop=()),                # y / acc stay in registers: 156 VGPRs, three waves per SIMD
+    "nopark_w4": dict(extra=["-DMVRL_NO_PARK", "-DMVRL_MIN_WAVES=4"], drop=()),   # 128-VGPR cap without parking: scratch spills
+    "park6k": dict(extra=["-DMVRL_PARK_FLOAT4S=384"], drop=()),       # 6 KB of LDS per wave: lets a fifth wave in where VGPRs allow
     "w2": dict(extra=["-DMVRL_MIN_WAVES=2"], drop=()),
     "w3": dict(extra=["-DMVRL_MIN_WAVES=3"], drop=()),
     "w4": dict(extra=["-DMVRL_MIN_WAVES=4"], drop=()),                # spills
     "ilp": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp"], drop=()),
+    "bias0": dict(extra=["-mllvm", "-amdgpu-schedule-metric-bias=0"], drop=()),
     "ilpw3": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-DMVRL_MIN_WAVES=3"], drop=()),
 }
 
