@@ -227,10 +227,10 @@ def main():
             h.count_launches(steps)
             return
         if stepper is not None:
-            stepper.fork()
+            # every timed / warm-up region starts and ends with a device-wide synchronize, so the chains need no fork from
+            # or join with the current stream here (each cross-stream wait costs ~10-20 us on the GPU's command processor)
             for k in range(steps):
                 stepper.step(ring[k % RING])
-            stepper.join()
             return
         for k in range(steps):
             env.step_tensors(ring[k % RING])
@@ -286,12 +286,29 @@ def main():
         if pd_obj is not None:
             pd_steps.zero_()
         sync()
-        h.timing_begin(stream)
-        t0 = time.perf_counter()
-        run_plain(K)
-        kern_ms, launches = h.timing_end(stream)
-        sync()
-        elapsed = time.perf_counter() - t0
+        if stepper is not None:
+            # HIP events on the streams the kernels are launched on: one pair per chain; the region's GPU time is the span
+            # from the earliest begin event to the latest end event
+            e0 = [torch.cuda.Event(enable_timing=True) for _ in stepper.streams]
+            e1 = [torch.cuda.Event(enable_timing=True) for _ in stepper.streams]
+            l0 = h.launch_count()
+            t0 = time.perf_counter()
+            for ev, st_ in zip(e0, stepper.streams):
+                ev.record(st_)
+            run_plain(K)
+            for ev, st_ in zip(e1, stepper.streams):
+                ev.record(st_)
+            sync()
+            elapsed = time.perf_counter() - t0
+            kern_ms = max(a.elapsed_time(b) for a in e0 for b in e1)
+            launches = h.launch_count() - l0
+        else:
+            h.timing_begin(stream)
+            t0 = time.perf_counter()
+            run_plain(K)
+            kern_ms, launches = h.timing_end(stream)
+            sync()
+            elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -315,8 +332,7 @@ def main():
         if pd_obj is not None:   # whole episodes per launch: count the env steps that were really taken
             value = med["pd_steps"] / elapsed
             steps_per_region = med["pd_steps"] / (world * n)
-        # HIP events on the launch stream bracket the K steps of the median repeat: time per env step of the batch.
-        # (With chains the begin event is recorded before the chains fork and the end event after they have joined.)
+        # HIP events on the launch stream(s) bracket the K steps of the median repeat: time per env step of the batch.
         per_step_s = kern_ms * 1e-3 / max(1e-9, steps_per_region)
         achieved = wl["bytes"] * n / per_step_s / 1e9
         khash = build.source_hash()

@@ -199,8 +199,13 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     float o[11];
 #pragma unroll
     for (int q = 0; q < 11; q++) o[q] = out.o[q];
+#ifndef MVRL_AUV_SKIP   /* traffic-attribution probe builds (tools/variants.py auvskip*): bit 0 hist, 1 obs, 2 reward/done, 3 state */
+#define MVRL_AUV_SKIP 0
+#endif
+    if (!(MVRL_AUV_SKIP & 4)) {
     io.reward[i] = out.reward;
     io.done[i] = done ? (time_up ? 3 : 1) : 0;  // bit 0 = done, bit 1 = time limit (else: bounds exceeded)
+    }
     if (io.aux) {  // timeHistory: Fx Fy N u_current v_current rmsAc r0..r4 (:389-403)
         float* ax = io.aux + (size_t)i * 11;
         ax[0] = out.Fg0; ax[1] = out.Fg1; ax[2] = out.Fh2; ax[3] = out.curx; ax[4] = out.cury; ax[5] = out.rms;
@@ -225,10 +230,13 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
         observe_auv(p, x, y, psi, vx, vy, r, tx, ty, tgt, herr_o, perr_ox, perr_oy, o);
     } else {
         // only the ring slot that changed is written back
+        if (!(MVRL_AUV_SKIP & 1)) {
 #pragma unroll
         for (int k = 0; k < 3; k++) ST(AV_HIST + 3 * slot + k) = (k == 0) ? a0 : ((k == 1) ? a1 : a2);
+        }
     }
 #if MVRL_AUV_LDS_OBS
+    if (!(MVRL_AUV_SKIP & 2))
     {   // Row-major [n, 11] observations: written lane-by-lane each store instruction scatters 4-byte pieces over 44-byte
         // strides (partial cache lines).  Transposing the wave's 64 x 11 tile through LDS turns them into 11 stores of
         // 256 contiguous bytes.  Wave-private region, stride 11 (odd) -> conflict-free; only the tail wave of the grid
@@ -253,8 +261,10 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
 #pragma unroll
     for (int q = 0; q < 11; q++) io.obs[(size_t)i * 11 + q] = o[q];
 #endif
+    if (!(MVRL_AUV_SKIP & 8)) {
     ST(AV_X) = x; ST(AV_Y) = y; ST(AV_PSI) = psi; ST(AV_VX) = vx; ST(AV_VY) = vy; ST(AV_R) = r;
     ST(AV_HERR_O) = herr_o; ST(AV_PERR_O) = perr_ox; ST(AV_PERR_O + 1) = perr_oy;
+    }
     if (cyl || (done && io.auto_reset)) ST(AV_TGT) = tgt;   // the target only changes on way-point switches / new episodes
     if (cyl) ST(AV_IWP) = pack_int(iwp);
     ST(AV_ISTEP) = pack_int(istep);

@@ -52,7 +52,9 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fm
 __device__ __forceinline__ float mod_two_pi(float x) {
     float q = floorf(x * MVRL_INV_TWO_PI);
     float r = fmaf(-q, MVRL_TWO_PI_HI, x);
-    r = fmaf(-q, MVRL_TWO_PI_LO, r);
+#if !MVRL_F64
+    r = fmaf(-q, MVRL_TWO_PI_LO, r);   // fp32: HI + LO is the reference's fp64 2*pi.  fp64: see angle_error
+#endif
     // q may be off by one when x sits next to a multiple of 2*pi
     r = (r < 0.f) ? r + MVRL_TWO_PI_HI : r;
     r = (r >= MVRL_TWO_PI_HI) ? r - MVRL_TWO_PI_HI : r;
@@ -66,7 +68,12 @@ __device__ __forceinline__ float angle_error(float psi_d, float psi) {
     const float d = psi_d - psi;
     const float q = rintf(d * MVRL_INV_TWO_PI);
     float r = fmaf(-q, MVRL_TWO_PI_HI, d);
+#if !MVRL_F64
     r = fmaf(-q, MVRL_TWO_PI_LO, r);
+#endif
+    // fp64 build: the reference's `%` is the EXACT remainder by the fp64 number 2*pi (not by the real 2 pi); the fma above is
+    // that remainder exactly, and adding the LO correction would decide the +-pi tie differently from the reference
+    // (golden G1 holds 4 such cases; tests/test_gpu_edge.py)
     r = (r >= MVRL_PI) ? r - MVRL_TWO_PI_HI : r;
     r = (r < -MVRL_PI) ? r + MVRL_TWO_PI_HI : r;
     return r;

@@ -432,7 +432,12 @@ hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& f
         return hipGetLastError();
     }
 #endif
-    if (io.k_steps > 1) {  // fused multi-step launch
+    // one instance for single steps and fused multi-step launches (see launch_rov6_step): same binary, same roundings
+#if !MVRL_F64 && !defined(MVRL_SEPARATE_SINGLE)
+    {
+#else
+    if (io.k_steps > 1) {
+#endif
 #define MVRL_L3M(PPT, Z, F) hipLaunchKernelGGL((rov3_step_kernel<PPT, Z, F, 0, true>), grid, block, 0, stream, p, io, fl)
         if (baked) {
             if (zoh) { if (flow) MVRL_L3M(const Rov3Baked*, true, true); else MVRL_L3M(const Rov3Baked*, true, false); }

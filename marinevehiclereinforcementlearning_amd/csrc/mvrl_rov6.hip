@@ -878,7 +878,14 @@ hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& f
         return hipGetLastError();
     }
 #endif
-    if (io.k_steps > 1) {  // fused multi-step launch: instantiated for the baked and sym flavours (the caller loops otherwise)
+    // The baked and sym flavours have ONE instance for single steps and fused multi-step launches (k_steps is a run-time
+    // trip count): a roll-out of K steps and K single-step launches execute the same binary, hence the same roundings
+    // (fast-math contraction is decided per instance; two instances of the same source may differ in the last bit).
+#if !MVRL_F64 && !defined(MVRL_SEPARATE_SINGLE)
+    if (baked || sym) {
+#else
+    if (io.k_steps > 1) {
+#endif
 #define MVRL_L6M(PPT, Z, F) hipLaunchKernelGGL((rov6_step_kernel<PPT, true, Z, F, 0, true>), grid, block, 0, stream, p, io, fl)
         if (baked) {
             if (zoh) { if (flow) MVRL_L6M(const Rov6Baked*, true, true); else MVRL_L6M(const Rov6Baked*, true, false); }

@@ -134,6 +134,32 @@ class OutputGather:
         return self.unpack()
 
 
+class TorchStreams:
+    """The stream / event operations GatherPipeline needs, on HIP streams through torch."""
+
+    def __init__(self, side):
+        self.side = side
+
+    def main(self):
+        return torch.cuda.current_stream()
+
+    def new_event(self):
+        return torch.cuda.Event()
+
+    def record(self, ev, stream):
+        ev.record(stream)
+
+    def wait(self, stream, ev):
+        stream.wait_event(ev)          # refers to the event's most recent record at THIS moment (HIP semantics)
+
+    def run(self, stream, fn):
+        with torch.cuda.stream(stream):
+            fn()                       # fn enqueues its kernels / collectives on `stream`
+
+    def join(self, stream, other):
+        stream.wait_stream(other)
+
+
 class GatherPipeline:
     """Step k+1 overlapped with the gather of step k: two message buffers, the exchange on a side stream.
 
@@ -144,38 +170,36 @@ class GatherPipeline:
 
     Ordering (events, no host synchronisation): the producer of step k may only overwrite buffer k & 1 once the exchange
     of step k-2 - the previous user of that buffer - has finished (`ev_gather[b]`); the exchange of step k starts once
-    the producer has finished (`ev_step[b]`).  Both events of a buffer are re-recorded every second step; a wait only
-    ever refers to the most recent record, which is the one it needs.  `streams=None` runs the same logic with CPU
-    tensors (tests): the callbacks then run in program order and `log` records it."""
+    the producer has finished (`ev_step[b]`).  Both events of a buffer are re-recorded every second step; a wait refers
+    to the most recent record at the moment it is enqueued, which is the one it needs.  `streams` is the stream backend:
+    TorchStreams(side) on the GPU; tests drive the same protocol through a simulated asynchronous backend that executes
+    the queued operations in random legal orders and checks that no buffer is overwritten before it was sent
+    (tests/test_distributed_cpu.py).  Without a backend everything runs in program order (CPU tensors)."""
 
-    def __init__(self, gathers, side_stream=None, log=None):
+    def __init__(self, gathers, side_stream=None, streams=None):
         assert len(gathers) == 2
-        self.g, self.side, self.k, self.log = gathers, side_stream, 0, log
-        self.cuda = side_stream is not None
-        if self.cuda:
-            self.ev_step = [torch.cuda.Event() for _ in range(2)]
-            self.ev_gather = [torch.cuda.Event() for _ in range(2)]
+        self.g, self.k = gathers, 0
+        self.s = streams if streams is not None else (TorchStreams(side_stream) if side_stream is not None else None)
+        if self.s is not None:
+            self.ev_step = [self.s.new_event() for _ in range(2)]
+            self.ev_gather = [self.s.new_event() for _ in range(2)]
 
     def step(self, produce):
         """produce(out_views) enqueues the env step that writes this step's message.  Returns the buffer index used."""
         b = self.k & 1
-        if self.cuda:
-            main = torch.cuda.current_stream()
-            if self.k >= 2:
-                main.wait_event(self.ev_gather[b])         # buffer b is free once gather k-2 has finished
-            produce(self.g[b].out_views())
-            self.ev_step[b].record(main)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.ev_step[b])
-                self.g[b].exchange()
-                self.ev_gather[b].record(self.side)
+        g = self.g[b]
+        if self.s is None:
+            produce(g.out_views())
+            g.exchange()
         else:
-            if self.log is not None:
-                self.log.append(("produce", self.k, b))
-            produce(self.g[b].out_views())
-            if self.log is not None:
-                self.log.append(("exchange", self.k, b))
-            self.g[b].exchange()
+            s, main, side = self.s, self.s.main(), self.s.side
+            if self.k >= 2:
+                s.wait(main, self.ev_gather[b])            # buffer b is free once gather k-2 has finished
+            s.run(main, lambda: produce(g.out_views()))
+            s.record(self.ev_step[b], main)
+            s.wait(side, self.ev_step[b])
+            s.run(side, g.exchange)
+            s.record(self.ev_gather[b], side)
         self.k += 1
         return b
 
@@ -184,8 +208,8 @@ class GatherPipeline:
         return self.g[(self.k - 1) & 1]
 
     def drain(self):
-        if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.side)
+        if self.s is not None:
+            self.s.join(self.s.main(), self.s.side)
 
 
 def rccl_info(backend, local_rank):

@@ -39,6 +39,24 @@ typedef REAL real;
 
 #define TWO_PI 6.283185307179586476925286766559
 
+/* Distance-to-discontinuity bookkeeping (tests only): while tl_margin points at a record, every RHS evaluation lowers
+ * the record's entries to the smallest distance seen between the trajectory and a point where the reference's
+ * right-hand side JUMPS (or, entry 4, amplifies rounding without bound):
+ *   [0] |e - eOld| of a PID axis at a call with t - tOld <= 1e-9 (6DoF.py:64-66: dedt = +-(that)/1e-9 -> the demand sits
+ *       on the +-umax rail given by the SIGN of a difference of two nearby errors); exact zeros (vehicle at rest) excluded
+ *   [1] | |rpm| / deadband - 1 |  of a thruster after saturation (limit(), 6DoF.py:271-275: |rpm| < 300 -> 0)
+ *   [2] | |e| - windup |  of an axis whose integral is non-zero (eInt[|e| > windup] = 0, 6DoF.py:68)
+ *   [3] pi - |yaw error|  (angleError's branch at +-pi, resources.py:92-95)
+ *   [4] |cos(theta)|      (J2 ~ 1/cos(theta), resources.py:116-132; below 1e-6 the guard itself switches)
+ * A trajectory computed in another precision may legitimately leave the reference trajectory only where one of these
+ * was within that precision's rounding of the quantity concerned. */
+#define ORC_N_MARGIN 5
+static __thread double* FN(tl_margin) = 0;
+static inline void margin_note(int k, double v) {
+    double* m = FN(tl_margin);
+    if (m && v < m[k]) m[k] = v;
+}
+
 static inline real r_abs(real x) { return x < 0 ? -x : x; }
 static inline real r_sign(real x) { return (real)((x > 0) - (x < 0)); }
 static inline real r_max(real a, real b) { return a > b ? a : b; }
@@ -87,6 +105,7 @@ static inline void g2v(const real axes[9], const real v[3], real out[3]) {
 void FN(orc_coord_transform6)(real phi, real theta, real psi, real J[36]) {
     real sp = r_sin(phi), cp = r_cos(phi), st = r_sin(theta), ct = r_cos(theta), ss = r_sin(psi), cs = r_cos(psi);
     real cd = ct;
+    margin_note(4, (double)r_abs(ct));
     if (r_abs(cd) < (real)1e-12) cd = (real)1e-6;
     else if (r_abs(cd) < (real)1e-6) cd = (real)1e-6 * r_sign(cd);
     memset(J, 0, 36 * sizeof(real));
@@ -119,7 +138,9 @@ static void pid_law(int n, const real* e, double t, pid_t_* s, const double* kp,
     real den = (real)(dtp > 1e-9 ? dtp : 1e-9);
     for (int i = 0; i < n; i++) {
         real dedt = (e[i] - s->eold[i]) / den;
+        if (dtp <= 1e-9 && e[i] != s->eold[i]) margin_note(0, (double)r_abs(e[i] - s->eold[i]));
         s->eint[i] += (real)0.5 * (s->eold[i] + e[i]) * (real)dtp;
+        if (s->eint[i] != 0) margin_note(2, (double)r_abs(r_abs(e[i]) - (real)windup[i]));
         if (r_abs(e[i]) > (real)windup[i]) s->eint[i] = 0;
         real u = (real)kp[i] * e[i] + (real)kd[i] * dedt + (real)ki[i] * s->eint[i];
         u = r_max(-(real)umax[i], r_min((real)umax[i], u));
@@ -135,6 +156,7 @@ void FN(orc_pid6)(const mvrl_rov6_params* p, const real sp[6], const real pose[6
     e[0] = sp[0] - pose[0]; e[1] = sp[1] - pose[1]; e[2] = sp[2] - pose[2];
     e[3] = sp[3] - pose[3]; e[4] = sp[4] - pose[4];
     e[5] = FN(orc_angle_error)(sp[5], pose[5]);
+    margin_note(3, 3.14159265358979323846 - (double)r_abs(e[5]));
     pid_law(6, e, t, s, p->kp, p->ki, p->kd, p->windup, p->umax, out);
 }
 
@@ -152,6 +174,7 @@ void FN(orc_alloc6)(const mvrl_rov6_params* p, const real axes[9], const real gc
 
 static inline real limit_rpm(real x, real rmax, real dead) { /* 6DoF.py:271-275 */
     real r = r_max(-rmax, r_min(rmax, x));
+    margin_note(1, (double)r_abs(r_abs(r) / dead - 1));
     if (r_abs(r) < dead) r = 0;
     return r;
 }
@@ -258,6 +281,7 @@ static void ctrl3(const mvrl_rov3_params* P, double t, const real y[6], const re
                   real rpm[4]) {
     real psi = y[2];
     real e[3] = {sp[0] - y[0], sp[1] - y[1], FN(orc_angle_error)(sp[2], psi)};
+    margin_note(3, 3.14159265358979323846 - (double)r_abs(e[2]));
     real cvv[3];
     pid_law(3, e, t, pid, P->kp, P->ki, P->kd, P->windup, P->umax, cvv);
     real c = r_cos(psi), s = r_sin(psi);
@@ -583,7 +607,8 @@ int FN(orc_rov_step)(int dof, const mvrl_rov6_params* p6, const mvrl_rov3_params
                      int32_t* has_old, int32_t* istep, double* time,
                      const real* flow_table, int f_nt, int f_ny, int f_nx, double f_dt, double f_dx, double f_dy,
                      const real* toffset,
-                     real* obs, real* reward, uint8_t* done, real* gcf_out, real* rpm_out, int64_t* nfev_out) {
+                     real* obs, real* reward, uint8_t* done, real* gcf_out, real* rpm_out, int64_t* nfev_out,
+                     double* margins_out /* [n][ORC_N_MARGIN] smallest distances of this step, or NULL */) {
     int ns = 2 * dof, nthr = dof == 6 ? 8 : 4, nobs = dof == 6 ? 9 : 5, npath = dof == 6 ? 6 : 4;
     int status = 0;
 #pragma omp parallel for schedule(static) reduction(min : status)
@@ -612,8 +637,13 @@ int FN(orc_rov_step)(int dof, const mvrl_rov6_params* p6, const mvrl_rov3_params
         c.dof = dof; c.zoh = (integrator == 0 && control_mode == MVRL_CTRL_ZOH); c.p6 = p6; c.p3 = p3; c.sp = spe;
         c.pid = &pid; c.cur = cur;
         double t0 = time[e] - dt;
+        if (margins_out) {
+            for (int i = 0; i < ORC_N_MARGIN; i++) margins_out[e * ORC_N_MARGIN + i] = 1e300;
+            FN(tl_margin) = margins_out + e * ORC_N_MARGIN;
+        }
         if (integrator == 0) integrate_rk4(&c, t0, dt, n_sub, ye);
         else if (integrate_rk45(&c, t0, time[e], dt, 1e-3, 1e-3, ye) != 0) status = -1;
+        FN(tl_margin) = 0;
         if (dof == 6) for (int i = 3; i < 6; i++) ye[i] = py_mod(ye[i], (real)TWO_PI); /* 6DoF.py:560 */
         else ye[2] = py_mod(ye[2], (real)TWO_PI);                                      /* 3DoF.py:480 */
         if (dof == 6) FN(orc_obs6)(p6, ye, path + e * npath, spe, obs + e * nobs);

@@ -219,6 +219,10 @@ class OracleRovEnv:
         self.gcf = np.zeros((n, dof), dt_)
         self.rpm = np.zeros((n, self.nthr), dt_)
         self.nfev = np.zeros(n, np.int64)
+        # smallest distance between each env's trajectory and a discontinuity of the reference's RHS during the LAST step
+        # (mvrl_oracle.c "Distance-to-discontinuity bookkeeping"): [sign of a zero-dt PID increment, thruster dead-band,
+        # integrator wind-up, yaw-error branch, |cos(theta)|]
+        self.margins = np.full((n, 5), np.inf)
 
     def reset(self, init, toffset=None):
         """init [n, init_dim]: wp0, wp1, target angles (see include/mvrl.h).  Mirrors 6DoF.py:485-529."""
@@ -251,7 +255,7 @@ class OracleRovEnv:
         f.restype = C.c_int
         f.argtypes = ([C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_double] + [C.c_int] * 5 + [C.c_void_p] * 10
                       + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
-                      + [C.c_void_p] * 6)
+                      + [C.c_void_p] * 7)
         fl = self.flow
         st = f(self.dof, C.addressof(o.rov6), C.addressof(o.rov3), self.n, float(self.dt),
                0 if self.integrator == "rk4" else 1, int(self.n_sub), int(self.control_mode), int(self.fixed_sp),
@@ -264,7 +268,7 @@ class OracleRovEnv:
                0 if fl is None else fl.table.shape[2], 0.0 if fl is None else fl.dt, 0.0 if fl is None else fl.dx,
                0.0 if fl is None else fl.dy, self.toffset.ctypes.data,
                obs.ctypes.data, rew.ctypes.data, done.ctypes.data, self.gcf.ctypes.data, self.rpm.ctypes.data,
-               self.nfev.ctypes.data)
+               self.nfev.ctypes.data, self.margins.ctypes.data)
         if st != 0:
             raise RuntimeError("oracle RK45: step size too small")
         return obs, rew, done

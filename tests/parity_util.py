@@ -1,0 +1,113 @@
+"""Outlier accounting for fp32-vs-fp64 trajectory comparisons.
+
+The closed loop the reference integrates has hard discontinuities (oracle/mvrl_oracle.c, "Distance-to-discontinuity
+bookkeeping"): at the RK stages with t - tOld = 0 the PID derivative is (e - eOld) / 1e-9, so the demand sits on the
++-umax rail chosen by the SIGN of an increment that can be arbitrarily small; thrusters below 300 rpm are switched off;
+the integrator is zeroed beyond the wind-up limit; the yaw error jumps by 2 pi at +-pi; J2 divides by cos(theta).
+An fp32 trajectory may leave the fp64 one ONLY where one of these was within fp32 rounding of the quantity that decides
+it.  `OutlierAudit` makes that a checked statement: the oracle reports, per env and step, the smallest distance to each
+discontinuity; every env that first exceeds the tolerance at step s must have come closer than the stated fp32 bound to
+one of them at some step <= s.  Envs beyond tolerance WITHOUT such an approach fail the test.
+"""
+import numpy as np
+
+# fp32 bounds, in the units of oracle.OracleRovEnv.margins.  Calibrated on 6 x 4096 envs x 25 steps (tools/margin_probe.py,
+# gpurun_out/r2_margins*.log): the largest distance seen on an env that jumped off x ~3.
+F32_BOUNDS = np.array([
+    6e-8,    # |e - eOld| at a zero-dt PID call [m or rad]: the increment is h/2 x (pose rate); the rate's fp32 error is ~1e-7 x |terms|
+    3e-4,    # | |rpm| / 300 - 1 |: the dead-band acts on demands of O(1..40 N) whose fp32 error is ~1e-6 x the terms of Ainv b
+    1e-4,    # | |e| - windup | [m or rad]
+    1e-4,    # pi - |yaw error| [rad]
+    5e-2,    # |cos(theta)|: 1 / cos(theta) amplifies fp32 rounding 20 x and more
+])
+# 3-DoF: yaw inertia 0.28 kg m^2 against 100 N m of yaw demand -> yaw rates of tens of rad/s, whose fp32 rounding enters every
+# pose rate through J(psi): jumps were seen at increments up to 1.9e-7 (16384 envs x 60 steps)
+F32_BOUNDS_3DOF = F32_BOUNDS * np.array([5.0, 1, 1, 1, 1])
+
+
+def bounds_for(dof):
+    return F32_BOUNDS if dof == 6 else F32_BOUNDS_3DOF
+
+
+NAMES = ["pid-increment sign", "thruster dead-band", "wind-up limit", "yaw-error branch", "cos(theta)"]
+# An env whose error stays below this never jumped: it drifted past the tolerance by accumulated rounding (the closed loop
+# multiplies pose rounding by K_D / h ~ 400..800 every sub-step; the smallest jump, one thruster crossing its dead-band for
+# one stage at n_sub 8, moves a velocity by 7e-5).  Such envs are counted separately and bounded in number.
+SMOOTH_TOL = 6e-5
+
+
+class OutlierAudit:
+    """Two thresholds: `tol` (the parity tolerance: envs beyond it are COUNTED) and SMOOTH_TOL (an env beyond it JUMPED:
+    the step at which that first happens must have passed - in that step or the one before - within the fp32 bound of a
+    discontinuity).  Envs beyond tol that never pass SMOOTH_TOL drifted (accumulated rounding) and are bounded in number."""
+
+    def __init__(self, n, tol, bounds=None, dof=6):
+        self.n, self.tol, self.bounds = n, tol, np.asarray(bounds_for(dof) if bounds is None else bounds, float)
+        self.first_bad = np.full(n, -1)                               # step at which the env first exceeded tol
+        self.first_jump = np.full(n, -1)                              # ... first exceeded SMOOTH_TOL
+        self.margin_at_jump = np.full((n, len(self.bounds)), np.inf)  # smallest distances during that step and the one before
+        self.err_at_jump = np.zeros(n)
+        self.max_err = np.zeros(n)
+        self.prev = np.full((n, len(self.bounds)), np.inf)
+        self.step_no = 0
+        self.worst_good = 0.0
+        self.near_steps = 0.0                                         # env-steps spent within the bounds of a discontinuity
+
+    def update(self, err, margins):
+        """err [n]: this step's scaled error per env; margins [n, 5]: the oracle's distances during this step."""
+        margins = np.asarray(margins, float)
+        newly = (err > self.tol) & (self.first_bad < 0)
+        self.first_bad[newly] = self.step_no
+        jump = (err > SMOOTH_TOL) & (self.first_jump < 0)
+        self.first_jump[jump] = self.step_no
+        self.margin_at_jump[jump] = np.minimum(margins, self.prev)[jump]
+        self.err_at_jump[jump] = err[jump]
+        self.max_err = np.maximum(self.max_err, err)
+        ok = self.first_bad < 0
+        if ok.any():
+            self.worst_good = max(self.worst_good, float(err[ok].max()))
+        self.near_steps += float((margins < self.bounds).any(axis=1).mean())
+        self.prev = margins
+        self.step_no += 1
+
+    @property
+    def bad(self):
+        return self.first_bad >= 0
+
+    @property
+    def jumped(self):
+        return self.first_jump >= 0
+
+    def explained(self):
+        return self.jumped & (self.margin_at_jump < self.bounds).any(axis=1)
+
+    def smooth(self):
+        return self.bad & ~self.jumped
+
+    def unexplained(self):
+        return self.jumped & ~self.explained()
+
+    def near_share_per_step(self):
+        return self.near_steps / max(1, self.step_no)
+
+    def report(self):
+        bad = np.nonzero(self.bad)[0]
+        ex, sm = self.explained(), self.smooth()
+        lines = [f"{len(bad)} / {self.n} envs beyond {self.tol:g}: {int(ex.sum())} jumped next to a discontinuity, {int(sm.sum())} drifted (never beyond "
+                 f"{SMOOTH_TOL:g}), {int(self.unexplained().sum())} jumped unexplained; per step {100 * self.near_share_per_step():.3f} % of all envs "
+                 f"are within the fp32 bounds of a discontinuity; worst error among the envs within tolerance {self.worst_good:.1e}"]
+        for i in bad[:60]:
+            if sm[i]:
+                lines.append(f"  env {i:6d} beyond tol from step {self.first_bad[i]:3d}, max err {self.max_err[i]:.1e}   (drift)")
+                continue
+            ratios = self.margin_at_jump[i] / self.bounds
+            k = int(np.argmin(ratios))
+            lines.append(f"  env {i:6d} jumped at step {self.first_jump[i]:3d} to err {self.err_at_jump[i]:.1e} (max {self.max_err[i]:.1e}): closest = "
+                         f"{NAMES[k]} at {self.margin_at_jump[i, k]:.2e} ({ratios[k]:.2f} x bound){'' if ex[i] else '   <-- UNEXPLAINED'}")
+        return "\n".join(lines)
+
+    def assert_explained(self, max_share=None, max_smooth_share=0.002):
+        assert not self.unexplained().any(), "envs that jumped off the fp64 trajectory without a discontinuity within fp32 reach:\n" + self.report()
+        assert self.smooth().mean() <= max_smooth_share, self.report()
+        if max_share is not None:
+            assert self.bad.mean() <= max_share, self.report()

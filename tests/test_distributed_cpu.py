@@ -139,3 +139,132 @@ def test_gather_single_process_passthrough():
     g.exchange()
     o, r, d = g.unpack()
     assert float(o.min()) == 2.0 and float(r.max()) == 3.0 and int(d.sum()) == 5
+
+
+# ---- GatherPipeline: step k+1 overlapped with gather k on two buffers (bench.py --gpus N, with_gather) --------------------
+class _SimStreams:
+    """Asynchronous two-stream machine with HIP's event semantics, for testing the pipeline's ordering protocol without a
+    GPU: operations are QUEUED per stream at call time and EXECUTED later by `drain_random`, which repeatedly picks a
+    random stream whose head operation is allowed to run.  record(ev) bumps the event's version when it executes;
+    wait(ev) captures, at enqueue time, the version of the most recent record ENQUEUED so far and blocks its stream until
+    that version has executed."""
+
+    def __init__(self, rng):
+        self.rng = rng
+        self.q = {"main": [], "side": []}
+        self.side = "side"
+        self.enq = {}      # event -> versions enqueued
+        self.done = {}     # event -> versions executed
+
+    def main(self):
+        return "main"
+
+    def new_event(self):
+        ev = object()
+        self.enq[ev], self.done[ev] = 0, 0
+        return ev
+
+    def record(self, ev, stream):
+        self.enq[ev] += 1
+        ver = self.enq[ev]
+        self.q[stream].append(("record", ev, ver))
+
+    def wait(self, stream, ev):
+        self.q[stream].append(("wait", ev, self.enq[ev]))
+
+    def run(self, stream, fn):
+        self.q[stream].append(("run", fn, None))
+
+    def join(self, stream, other):
+        ev = self.new_event()
+        self.record(ev, other)
+        self.wait(stream, ev)
+
+    def drain_random(self):
+        while self.q["main"] or self.q["side"]:
+            ready = []
+            for name, ops in self.q.items():
+                if ops and (ops[0][0] != "wait" or self.done[ops[0][1]] >= ops[0][2]):
+                    ready.append(name)
+            assert ready, "deadlock: every stream waits on an event nobody will record"
+            name = ready[int(self.rng.integers(len(ready)))]
+            kind, a, ver = self.q[name].pop(0)
+            if kind == "run":
+                a()
+            elif kind == "record":
+                self.done[a] = ver
+
+
+class _TagGather:
+    """Stands in for OutputGather: the 'message' is a one-element tensor; exchange() ships whatever it holds."""
+
+    def __init__(self, sent):
+        self.buf = torch.zeros(1)
+        self.sent = sent
+
+    def out_views(self):
+        return self.buf
+
+    def exchange(self):
+        self.sent.append(float(self.buf[0]))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gather_pipeline_ordering_under_random_async_schedules(seed):
+    """40 steps through the two-buffer pipeline on the simulated asynchronous backend: in every legal execution order
+    message k must leave with the data of step k - i.e. producer k+2 never overwrites buffer k & 1 before gather k has
+    read it, and gather k never runs before producer k has written (event re-use at k >= 2 included)."""
+    rng = np.random.default_rng(seed)
+    sim = _SimStreams(rng)
+    sent = []
+    pipe = D.GatherPipeline([_TagGather(sent), _TagGather(sent)], streams=sim)
+    K = 40
+    for k in range(K):
+        pipe.step(lambda out, k=k: out.fill_(float(k + 1)))
+        if rng.random() < 0.3:          # the host sometimes runs far ahead, sometimes the device catches up
+            sim.drain_random()
+    pipe.drain()
+    sim.drain_random()
+    assert sent == [float(k + 1) for k in range(K)]
+
+
+def test_gather_pipeline_detects_a_missing_wait():
+    """The simulator is sharp enough to see the race the protocol prevents: without the `buffer free` wait some schedule
+    overwrites a message before it was sent."""
+    class Broken(D.GatherPipeline):
+        def step(self, produce):
+            b = self.k & 1
+            g, s = self.g[b], self.s
+            s.run(s.main(), lambda: produce(g.out_views()))       # no wait on ev_gather[b]
+            s.record(self.ev_step[b], s.main())
+            s.wait(s.side, self.ev_step[b])
+            s.run(s.side, g.exchange)
+            s.record(self.ev_gather[b], s.side)
+            self.k += 1
+    raced = False
+    for seed in range(20):
+        sim = _SimStreams(np.random.default_rng(seed))
+        sent = []
+        pipe = Broken([_TagGather(sent), _TagGather(sent)], streams=sim)
+        for k in range(12):
+            pipe.step(lambda out, k=k: out.fill_(float(k + 1)))
+        pipe.drain()
+        sim.drain_random()
+        raced |= sent != [float(k + 1) for k in range(12)]
+    assert raced
+
+
+def test_gather_pipeline_program_order_on_cpu_tensors():
+    g = [D.OutputGather(6, 3, torch.device("cpu")) for _ in range(2)]
+    pipe = D.GatherPipeline(g)
+    for k in range(5):
+        def produce(out, k=k):
+            o, r, d = out
+            o.fill_(float(k)); r.fill_(float(10 + k)); d.fill_(k % 2)
+        assert pipe.step(produce) == k & 1
+        o, r, d = pipe.latest().unpack()
+        assert float(o.min()) == k and float(r.max()) == 10 + k and int(d[0]) == k % 2
+        if k:                            # the other buffer still holds the previous step's message
+            o_prev, _, _ = g[(k - 1) & 1].unpack()
+            assert float(o_prev.max()) == k - 1
+    pipe.drain()

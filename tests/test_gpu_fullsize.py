@@ -112,3 +112,137 @@ def test_auvenv_half_turn_symmetry_at_full_size():
     assert worst_o < 1e-4, worst_o
     assert worst_r < 1e-4, worst_r
     ha.close(); hb.close()
+
+
+# ---- the instances bench.py times, at the size it times them, against the oracle -------------------------------------------
+def _bench_flow():
+    from marinevehiclereinforcementlearning_amd.flow import ReconstructedFlow
+    flow = ReconstructedFlow.synthetic(n_modes=8, n_time=2000, device=0)     # exactly bench.py's table
+    flow.scale(11., 1., 2., translate=(-1.65, -1.1))
+    return flow
+
+
+def test_benched_c4_instance_at_full_size_vs_oracle(oracle_mod):
+    """BASELINE configs[3] exactly as bench.py builds and steps it - MarineVecEnv("rov6", 1 048 576 envs, seed 12345,
+    n_substeps 4, FAITHFUL, fp32, baked constants, 2000-snapshot turbulence table, random Philox initial paths / attitudes /
+    time offsets, ring of uniform(-1,1) action batches from mvrl_fill_uniform_dev, two chains of lane ranges) - for 10 steps.
+    A fixed random subsample of 4096 lanes (whole batch positions: first / last wave, chain boundary included) is re-run by
+    the fp64 oracle from the same initial planes, actions and time offsets; tolerance 1e-5 with the discontinuity audit."""
+    import torch
+    from marinevehiclereinforcementlearning_amd.chains import ChainStepper
+    from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
+    from .parity_util import OutlierAudit
+    n, steps, seed = 1048576, 10, 12345
+    flow = _bench_flow()
+    env = MarineVecEnv("rov6", n, seed=seed, n_substeps=4, control_mode="faithful", flow=flow, device=0, infos="lean")
+    assert env.variant == "rov6/baked/faithful+flow"
+    h = env.handle
+    stream = torch.cuda.current_stream().cuda_stream
+    ring = torch.empty((8, n, 6), dtype=torch.float32, device="cuda")
+    for r in range(8):
+        h.fill_uniform_dev(ring[r].data_ptr(), n * 6, seed, r, -1.0, 1.0, stream)
+    env.reset_tensors()
+    rng = np.random.default_rng(3)
+    lanes = np.unique(np.concatenate([np.arange(64), np.arange(n - 64, n), np.arange(n // 2 - 64, n // 2 + 64),
+                                      rng.choice(n, 4096 - 256, replace=False)]))
+    st0 = env.get_state()
+    pl = P.STATE_PLANES[P.MODEL_ROV6]
+    init = np.concatenate([st0[pl["path"]][:, lanes].T, st0[pl["setpoint"]][3:, lanes].T], axis=1).astype(np.float64)
+    toff = st0[pl["toffset"]][lanes].astype(np.float64)
+    assert np.all(st0[pl["y"]] == 0) and toff.min() >= 0 and toff.max() > 1.0       # random offsets within flow.time[nT // 4]
+    ref = oracle_mod.OracleRovEnv(6, len(lanes), "f64", n_substeps=4, max_steps=250,
+                                  flow=oracle_mod.FlowTable(flow.table_uv().astype(np.float64), flow.dt, flow.dx, flow.dy))
+    ref_obs0 = ref.reset(init, toffset=toff)
+    obs_t = env._ensure_tensors()[0]
+    assert np.max(np.abs(obs_t[torch.as_tensor(lanes, device="cuda")].cpu().numpy() - ref_obs0)) < 1e-5
+    acts = ring[:, torch.as_tensor(lanes, device="cuda")].cpu().numpy().astype(np.float64)
+    stepper = ChainStepper(env, n_chains=2)
+    audit = OutlierAudit(len(lanes), 1e-5, dof=6)
+    for k in range(steps):
+        stepper.fork()
+        obs, rew, done = stepper.step(ring[k % 8])
+        stepper.join()
+        ref_obs, _, ref_done = ref.step(acts[k % 8])
+        y = env.get_state()[:12][:, lanes].T.astype(np.float64)
+        d = np.abs(y - ref.y)
+        d[:, 3:6] = np.minimum(d[:, 3:6], np.abs(d[:, 3:6] - 2 * np.pi))
+        audit.update((d / np.maximum(1.0, np.abs(ref.y))).max(axis=1), ref.margins)
+        on = ~audit.bad
+        o = obs[torch.as_tensor(lanes, device="cuda")].cpu().numpy()
+        assert np.max(np.abs(o - ref_obs)[on]) < 2e-5, k
+        assert not done.any().item() and not ref_done.any()
+    print("C4 at full size: " + audit.report())
+    audit.assert_explained(max_share=0.004, max_smooth_share=0.002)
+    assert torch.isfinite(obs).all().item()
+    env.close()
+
+
+def test_replicated_lanes_with_turbulence_at_full_size():
+    """The replication property on the flow-enabled baked instance (the one bench.py times): 64 prototypes (initial paths,
+    time offsets, action sequences) tiled over 1 048 576 lanes stay bit-identical wherever they sit."""
+    n, reps = 1048576, 1048576 // 64
+    flow = _bench_flow()
+    rng = np.random.default_rng(8)
+    proto_init = np.concatenate([(rng.random((64, 6)) - 0.5) * 2.0, rng.random((64, 3)) * 2 * np.pi], axis=1).astype(np.float32)
+    proto_toff = (rng.random(64) * 10.0).astype(np.float32)
+    proto_act = rng.uniform(-1, 1, size=(10, 64, 6)).astype(np.float32)
+    h = _lib.Handle(P.make_config("rov6", n, auto_reset=False, max_steps=10 ** 9, use_flow=True))
+    h.set_flow(flow.table_uv(), flow.dt, flow.dx, flow.dy)
+    assert h.variant == "rov6/baked/faithful+flow"
+    h.reset(init=np.tile(proto_init, (reps, 1)))
+    st = h.get_state()
+    st[P.STATE_PLANES[P.MODEL_ROV6]["toffset"]] = np.tile(proto_toff, reps)
+    h.set_state(st)
+    for s in range(10):
+        obs, _, _ = h.step(np.tile(proto_act[s], (reps, 1)))
+    st = h.get_state().reshape(-1, reps, 64)
+    assert np.isfinite(st).all() and np.abs(st[6:12]).max() > 1e-3        # the vehicles moved
+    assert np.array_equal(st, np.broadcast_to(st[:, :1, :], st.shape))
+    o = obs.reshape(reps, 64, -1)
+    assert np.array_equal(o, np.broadcast_to(o[:1], o.shape))
+    h.close()
+
+
+def test_benched_auv_instance_at_full_size_vs_oracle(oracle_mod):
+    """AuvEnv + turbulence as `bench.py --workload auv` builds it (1 048 576 envs, random Philox resets with the reference's
+    noise magnitudes switched off as in the bench, random actions): 4096 sampled lanes re-run by the fp64 oracle from the
+    same initial planes for 10 steps - poses, observations, rewards, done flags."""
+    import torch
+    from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
+    n, steps, seed = 1048576, 10, 12345
+    flow = _bench_flow()
+    env = MarineVecEnv("auv", n, seed=seed, flow=flow, device=0, infos="lean")
+    h = env.handle
+    ring = torch.empty((8, n, 3), dtype=torch.float32, device="cuda")
+    for r in range(8):
+        h.fill_uniform_dev(ring[r].data_ptr(), n * 3, seed, r, -1.0, 1.0, torch.cuda.current_stream().cuda_stream)
+    obs0 = env.reset_tensors().clone()
+    rng = np.random.default_rng(4)
+    lanes = np.unique(np.concatenate([np.arange(64), np.arange(n - 64, n), rng.choice(n, 4096 - 128, replace=False)]))
+    li = torch.as_tensor(lanes, device="cuda")
+    st0 = env.get_state()
+    pl = P.STATE_PLANES[P.MODEL_AUV]
+    init = np.zeros((len(lanes), 16))
+    init[:, :3] = st0[pl["pose"]][:3, lanes].T
+    init[:, 3] = st0[pl["heading_target"]][lanes]
+    init[:, 4] = st0[pl["toffset"]][lanes]
+    init[:, 5:] = st0[pl["mult"]][:, lanes].T
+    ref = oracle_mod.OracleAuvEnv(len(lanes), "f64", dt=env.dt, max_steps=250,
+                                  flow=oracle_mod.FlowTable(flow.table_uv().astype(np.float64), flow.dt, flow.dx, flow.dy))
+    assert np.max(np.abs(obs0[li].cpu().numpy() - ref.reset(init))) < 1e-5
+    acts = ring[:, li].cpu().numpy().astype(np.float64)
+    alive = np.ones(len(lanes), bool)
+    for k in range(steps):
+        obs, rew, done = env.step_tensors(ring[k % 8])
+        o_ref, r_ref, d_ref = ref.step(acts[k % 8])
+        d_gpu = done[li].cpu().numpy()
+        alive &= ((d_gpu != 0) == (d_ref != 0)) & (d_ref == 0)      # lanes that finished were auto-reset on the GPU: drop them
+        a = alive
+        pose = env.get_state()[:6][:, lanes].T.astype(np.float64)
+        dd = np.abs(pose - ref.pose)
+        dd[:, 2] = np.minimum(dd[:, 2], np.abs(dd[:, 2] - 2 * np.pi))
+        assert (dd / np.maximum(1.0, np.abs(ref.pose)))[a].max() < 1e-5, k
+        assert np.max(np.abs(obs[li].cpu().numpy() - o_ref)[a]) < 3e-5, k
+        assert np.max((np.abs(rew[li].cpu().numpy() - r_ref) / np.maximum(1.0, np.abs(r_ref)))[a]) < 3e-5, k
+    assert alive.mean() > 0.99
+    env.close()

@@ -24,6 +24,10 @@ VARIANTS = {
     "nopark": dict(extra=["-DMVRL_NO_PARK"], drop=()),                # y / acc stay in registers: 156 VGPRs, three waves per SIMD
     "nopark_w4": dict(extra=["-DMVRL_NO_PARK", "-DMVRL_MIN_WAVES=4"], drop=()),   # 128-VGPR cap without parking: scratch spills
     "park6k": dict(extra=["-DMVRL_PARK_FLOAT4S=384"], drop=()),       # 6 KB of LDS per wave: lets a fifth wave in where VGPRs allow
+    "auvskip1": dict(extra=["-DMVRL_AUV_SKIP=1"], drop=()),  # AuvEnv write-traffic attribution: no action-ring stores
+    "auvskip2": dict(extra=["-DMVRL_AUV_SKIP=2"], drop=()),  #   no observation stores
+    "auvskip4": dict(extra=["-DMVRL_AUV_SKIP=4"], drop=()),  #   no reward / done stores
+    "auvskip8": dict(extra=["-DMVRL_AUV_SKIP=8"], drop=()),  #   no pose / error-memory stores
     "w2": dict(extra=["-DMVRL_MIN_WAVES=2"], drop=()),
     "w3": dict(extra=["-DMVRL_MIN_WAVES=3"], drop=()),
     "w4": dict(extra=["-DMVRL_MIN_WAVES=4"], drop=()),                # spills
