@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--n-substeps", type=int, default=4)
     ap.add_argument("--control-mode", default="faithful", choices=["faithful", "zoh"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="f64 = the exactness build of the same kernels")
+    ap.add_argument("--flavour", default="baked", choices=["baked", "sym", "generic"],
+                    help="6-DoF kernel flavour: the reference's constants (literals), other BlueROV2-structured numbers "
+                         "(run-time constants, sparse forms), or arbitrary constants (dense 6 x 6 forms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=12345)
     args = ap.parse_args()
@@ -161,8 +164,13 @@ def main():
         if rank == 0 and not args.no_cpu_baseline and world == 1:
             flow_np = dict(table=flow.table_uv().astype(np.float64), dt=flow.dt, dx=flow.dx, dy=flow.dy)
 
+    vp = None
+    if wl["model"] == "rov6" and args.flavour != "baked":
+        from marinevehiclereinforcementlearning_amd import params as P_
+        vp = P_.rov6_params(m=12.0, Xuu=-19.0) if args.flavour == "sym" else P_.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3, m=12.0)
     env = MarineVecEnv(wl["model"], n, seed=args.seed, n_substeps=args.n_substeps, control_mode=args.control_mode,
-                       flow=flow, device=local_rank, env_offset=rank * n, infos="lean", precision=args.precision)
+                       flow=flow, device=local_rank, env_offset=rank * n, infos="lean", precision=args.precision,
+                       vehicle_params=vp)
     act_dim, obs_dim = env.action_space.shape[0], env.observation_space.shape[0]
     h = env.handle
     stream = torch.cuda.current_stream().cuda_stream

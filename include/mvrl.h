@@ -246,7 +246,9 @@ int mvrl_get_terminal_obs_dev(mvrl_handle* h, void* obs_dev, void* stream);
 /* ---- raw state (checkpoint / parity tests): SoA [state_words][n_envs] in the handle's precision.  Planes:
  *   ROV6 (41): y[12] eOld[6] eInt[6] setPoint[6] path[6] episode tOld time flowTimeOffset iStep
  *   ROV3 (24): y[6] eOld[3] eInt[3] setPoint[3] path[4] episode tOld time flowTimeOffset iStep
- *   AUV  (55): pose[6] headingTarget herr_o perr_o[2] mult[11] flowTimeOffset actionRing[30] iStep iWp episode
+ *   AUV  (56): pose[6] headingTarget herr_o perr_o[2] mult[11] flowTimeOffset actionRing[30] iStep iWp episode ringPhase
+ *              (the action of step iStep sits in ring slot (iStep - 1 + ringPhase) % 10: a new episode's ring continues
+ *              at the slot where the previous one stopped, so the envs of a wave keep writing one plane per step)
  * iStep / iWp / episode are integer bit patterns (int32 in a float slot / int64 in a double slot).  `episode` counts
  * the env's resets and is the counter of its Philox stream: random resets depend on (seed, global env id, episode)
  * only, not on how many launches the handle has issued - restoring a state restores the RNG position, and a sequence

@@ -18,7 +18,13 @@ enum {
     AV_TOFF = 21, AV_HIST = 22, AV_ISTEP = 52,
     AV_IWP = 53,    // AuvEnvCyl: way-point index (integer bit pattern); survives reset() like the reference's self.iWp
     AV_EPISODE = 54,  // number of resets of this env = counter of its Philox stream (see mvrl_rov6.hip)
-    AV_WORDS = 55
+    // Origin of the action ring: the action of step `istep` goes to slot (istep - 1 + phase) % 10.  A new episode starts
+    // where the old one stopped (phase' = next slot) instead of at slot 0, so the lanes of a wave - whose episodes end at
+    // different times - keep writing the SAME ring plane every step: one coalesced 256-B store instead of 64 scattered
+    // 4-byte ones, each of which costs a 32-B HBM sector (measured: 65 B/env of write traffic for 12 B of data).
+    // recentActions (verySimpleAuv.py:275, :353-355) is only ever reduced to per-component mean / std: order-free.
+    AV_PHASE = 55,
+    AV_WORDS = 56
 };
 
 // dataToState "V3" (verySimpleAuv.py:201-212); positionTarget = 0 (:241)
@@ -79,7 +85,7 @@ struct AuvLane {
     float mu[11];
     float hist[30];
     float toff;
-    int istep, iwp;
+    int istep, iwp, phase;
 };
 struct AuvStepOut {
     float o[11];
@@ -99,7 +105,7 @@ __device__ __forceinline__ void auv_step_core(const AuvDev& p, const FlowDev& fl
     const float time = (float)s.istep * dt;        // :267
     const bool time_up = s.istep >= max_steps;     // :270-272
     bool done = time_up;
-    const int slot = (s.istep - 1) % 10;           // recentActions.appendleft (:275) as a ring
+    const int slot = (s.istep - 1 + s.phase) % 10; // recentActions.appendleft (:275) as a ring starting at slot `phase`
     const int nh = s.istep < 10 ? s.istep : 10;
 #pragma unroll
     for (int j = 0; j < 10; j++) {
@@ -140,15 +146,21 @@ __device__ __forceinline__ void auv_step_core(const AuvDev& p, const FlowDev& fl
     s.herr_o = herr; s.perr_ox = perr0; s.perr_oy = perr1;                                  // :349-350
     float rms = 0.f;                                                                        // :353-355
     const float inv_nh = 1.0f / (float)nh;
+    bool valid[10];                                // the episode's last nh actions sit in slots phase .. phase + nh - 1 (mod 10)
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        const int d = j - s.phase;
+        valid[j] = (d < 0 ? d + 10 : d) < nh;
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float mean = 0.f;
 #pragma unroll
-        for (int j = 0; j < 10; j++) mean += (j < nh) ? s.hist[3 * j + k] : 0.f;
+        for (int j = 0; j < 10; j++) mean += valid[j] ? s.hist[3 * j + k] : 0.f;
         mean *= inv_nh;
         float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < 10; j++) { float d = s.hist[3 * j + k] - mean; ss += (j < nh) ? d * d : 0.f; }
+        for (int j = 0; j < 10; j++) { float d = s.hist[3 * j + k] - mean; ss += valid[j] ? d * d : 0.f; }
         rms += sqrtf(ss * inv_nh);
     }
     rms *= (1.0f / 3.0f);
@@ -173,6 +185,7 @@ __device__ __forceinline__ void auv_step_core(const AuvDev& p, const FlowDev& fl
         _Pragma("unroll") for (int q_ = 0; q_ < 11; q_++) (s).mu[q_] = ST(AV_MULT + q_);                               \
         _Pragma("unroll") for (int q_ = 0; q_ < 30; q_++) (s).hist[q_] = ST(AV_HIST + q_);                             \
         (s).istep = unpack_int(ST(AV_ISTEP));                                                                         \
+        (s).phase = unpack_int(ST(AV_PHASE));                                                                         \
         (s).toff = FLOW ? ST(AV_TOFF) : 0.f;                                                                          \
     } while (0)
 
@@ -227,6 +240,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
         for (int q = 0; q < 11; q++) ST(AV_MULT + q) = v[5 + q];
         perr_ox = tx - x; perr_oy = ty - y; herr_o = angle_error(tgt, psi);            // herr_o = None -> first call (:160-162)
         istep = 0;
+        ST(AV_PHASE) = pack_int((slot + 1) % 10);     // the new episode's ring continues at the next slot (see AV_PHASE)
         observe_auv(p, x, y, psi, vx, vy, r, tx, ty, tgt, herr_o, perr_ox, perr_oy, o);
     } else {
         // only the ring slot that changed is written back
@@ -374,6 +388,9 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_reset_kernel(const AuvDev p, f
     st[AV_TOFF * n] = v[4];
 #pragma unroll
     for (int q = 0; q < 30; q++) st[(AV_HIST + q) * n] = 0.f;
+    // the ring of the new episode starts where this env would have written next: envs that shared a slot keep sharing it
+    int ph = (unpack_int(st[AV_ISTEP * n]) + unpack_int(st[AV_PHASE * n])) % 10;
+    st[AV_PHASE * n] = pack_int(ph < 0 ? 0 : ph);
     st[AV_ISTEP * n] = pack_int(0);
     if (obs) {
         float o[11];
@@ -421,6 +438,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_rollout_kernel(const AuvDev p,
             for (int q = 0; q < 11; q++) s.mu[q] = v[5 + q];
             s.perr_ox = s.tx - s.x; s.perr_oy = s.ty - s.y; s.herr_o = angle_error(s.tgt, s.psi);
             s.istep = 0;
+            s.phase = (out.slot + 1) % 10;
             observe_auv(p, s.x, s.y, s.psi, s.vx, s.vy, s.r, s.tx, s.ty, s.tgt, s.herr_o, s.perr_ox, s.perr_oy, out.o);
         }
         float* orow = io.obs + ((size_t)k * n + i) * 11;
@@ -437,6 +455,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_rollout_kernel(const AuvDev p,
 #pragma unroll
     for (int q = 0; q < 30; q++) ST(AV_HIST + q) = s.hist[q];
     ST(AV_ISTEP) = pack_int(s.istep);
+    ST(AV_PHASE) = pack_int(s.phase);
 #undef ST
 }
 

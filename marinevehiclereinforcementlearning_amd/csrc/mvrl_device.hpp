@@ -84,8 +84,7 @@ __device__ __forceinline__ float angle_error(float psi_d, float psi) {
 __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
 #if MVRL_F64
     ::sincos(x, &s, &c);  // fp64 build: the library routine
-    return;
-#endif
+#else
 #ifdef MVRL_NATIVE_TRIG
     // hardware v_sin_f32 / v_cos_f32 (argument in revolutions): ~4x fewer issue slots, ~1e-6 absolute accuracy
     const float rev = x * MVRL_INV_TWO_PI;
@@ -108,6 +107,7 @@ __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
     float c1 = (n & 1) ? sn : cn;
     s = (n & 2) ? -s1 : s1;
     c = ((n + 1) & 2) ? -c1 : c1;
+#endif
 }
 
 // the step counter shares the SoA state buffer with the real-valued planes: stored as an integer bit pattern
@@ -252,7 +252,14 @@ __device__ __forceinline__ PT launder(PT p) {
     asm volatile("" : "+s"(p));
     return p;
 }
-
+// Row-by-row variant for the dense (generic) forms: the pointer is re-hidden together with a value the previous row
+// produced, so that the loads of row i cannot be issued (and their destinations kept alive) before row i - 1 is done -
+// an asm without such a data dependence floats to the top of the block, all rows' loads behind it.
+template <class PT>
+__device__ __forceinline__ PT launder_after(PT p, float& x) {
+    asm volatile("" : "+s"(p), "+v"(x));
+    return p;
+}
 }  // namespace mvrl
 #include "mvrl_baked.inc"
 namespace mvrl {
@@ -272,6 +279,7 @@ __device__ __forceinline__ float in_vgpr(float x) {
 
 // Baked flavour: `p->field` resolves to a static constexpr member, i.e. an instruction literal; nothing to launder.
 __device__ __forceinline__ const Rov6Baked* launder(const Rov6Baked* p) { return p; }
+__device__ __forceinline__ const Rov6Baked* launder_after(const Rov6Baked* p, float&) { return p; }
 __device__ __forceinline__ const Rov3Baked* launder(const Rov3Baked* p) { return p; }
 template <class PP, class T>
 __device__ __forceinline__ PP param_ptr(const T* pg) {

@@ -41,6 +41,6 @@ hipError_t launch_replay_add_sym(const float* obs, const float* next_obs, const 
 hipError_t launch_fill_uniform(float* dst, int64_t n, uint64_t seed, uint64_t counter, float lo, float hi,
                                hipStream_t stream);
 
-enum { R6_WORDS_ = 41, R3_WORDS_ = 24, AUV_WORDS_ = 55 };
+enum { R6_WORDS_ = 41, R3_WORDS_ = 24, AUV_WORDS_ = 56 };
 
 }  // namespace mvrl

@@ -117,7 +117,7 @@ __device__ __forceinline__ void allocate6(PP p, const Axes& a, const float* u, f
     } else {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            
+            if (i > 0) p = launder_after(p, cv[i - 1]);   // row by row: a handful of constants live at a time
             float c = p->Ainv[6 * i] * b[0];
 #pragma unroll
             for (int j = 1; j < 6; j++) c = fmaf(p->Ainv[6 * i + j], b[j], c);
@@ -223,6 +223,7 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
                       -p->gw[0] * t.cth * t.sph - p->gw[1] * t.sth};
 #pragma unroll
         for (int i = 0; i < 6; i++) {
+            if (i > 0) p = launder_after(p, R[i - 1]);
             float h = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; k++) h = fmaf(p->A[8 * i + k], F[k], h);
@@ -236,6 +237,7 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
         }
 #pragma unroll
         for (int i = 0; i < 6; i++) {
+            p = launder_after(p, i > 0 ? dy[6 + i - 1] : R[5]);
             float a = 0.f;
 #pragma unroll
             for (int j = 0; j < 6; j++) a = fmaf(p->minv[6 * i + j], R[j], a);
@@ -269,14 +271,16 @@ __device__ __forceinline__ Trig6 trig6(const float* y) {
 // sin/cos of the attitude at an RK stage whose angles differ from the sub-step's base angles by the small, known
 // increments d[3..5] (= c * k of the previous stage): rotate the base values by (cos d, sin d) from the [-pi/4, pi/4]
 // polynomials of sincos_f32 - no range reduction, no quadrant selection: 14 instructions per angle instead of ~35, three
-// of the four stages of every sub-step.  |d| <= pi/4 is checked per wave (the vehicle turns at < 5 rad/s, d = h * rate
-// ~ 0.1); a wave with a larger increment, and the fp64 build (whose parity bar is 1e-9), evaluate the stage in full.
+// of the four stages of every sub-step.  |d| <= pi/4 is checked per lane (the vehicle turns at < 5 rad/s, d = h * rate
+// ~ 0.1); a lane with a larger increment, and the fp64 build (whose parity bar is 1e-9), evaluate the stage in full.
 __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, const float* d) {
 #if MVRL_F64 || defined(MVRL_FULL_STAGE_TRIG)
     return trig6(yt);
 #else
     const float m = fmaxf(fmaxf(fabsf(d[3]), fabsf(d[4])), fabsf(d[5]));
-    if (__builtin_expect(__any(m > 0.78f), 0)) return trig6(yt);
+#ifdef MVRL_TRIG_WAVE_FALLBACK
+    if (__builtin_expect(__any(m > 0.78f), 0)) return trig6(yt);   // the whole wave evaluates the stage in full
+#endif
     Trig6 t;
     float sd[3], cd[3];
 #pragma unroll
@@ -290,6 +294,13 @@ __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, con
     t.sph = fmaf(b.cph, sd[0], b.sph * cd[0]); t.cph = fmaf(-b.sph, sd[0], b.cph * cd[0]);
     t.sth = fmaf(b.cth, sd[1], b.sth * cd[1]); t.cth = fmaf(-b.sth, sd[1], b.cth * cd[1]);
     t.sps = fmaf(b.cps, sd[2], b.sps * cd[2]); t.cps = fmaf(-b.sps, sd[2], b.cps * cd[2]);
+#ifndef MVRL_TRIG_WAVE_FALLBACK
+    // Lanes with a larger increment (an env spinning up next to gimbal lock: about one in a hundred under random actions)
+    // take the full evaluation as a DIVERGENT branch: the wave issues those ~80 instructions with one or two lanes enabled.
+    // The chip runs this kernel at its power limit, where an instruction's cost is the lanes it
+    // switches, not its issue slot - cheaper than sending all 64 lanes through the full evaluation whenever one needs it.
+    if (m > 0.78f) t = trig6(yt);
+#endif
     return t;
 #endif
 }
@@ -424,7 +435,7 @@ __device__ unsigned long long g_stamp_rt[5 * MVRL_STAMP_WAVES];   // s_memrealti
 // (tools/valu_dep.hip).  33 LDS instructions per sub-step against ~1450 VALU.
 #if !MVRL_F64 && !defined(MVRL_NO_PARK)
 #define MVRL_PARK_ON 1
-#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, SYM ? 4 : 1)
+#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, SYM ? 4 : 2)
 // LDS per block = 10 KB although the parked tiles need 6: 160 KB / 10 KB = 16 one-wave blocks per CU = exactly four waves
 // per SIMD.  A kernel instance that happens to need <= 96 VGPRs would otherwise get a FIFTH wave, and five waves rotate
 // over eight issue slots (tools/valu_dep.hip).

@@ -19,7 +19,7 @@ ABI_VERSION = 1
 MODEL_NAMES = {"auv": MODEL_AUV, "rov3": MODEL_ROV3, "rov6": MODEL_ROV6}
 #            act, obs, init, state_words, aux
 MAX_WAYPOINTS = 32
-MODEL_DIMS = {MODEL_AUV: (3, 11, 16, 55, 11), MODEL_ROV3: (3, 5, 5, 24, 7), MODEL_ROV6: (6, 9, 9, 41, 14)}
+MODEL_DIMS = {MODEL_AUV: (3, 11, 16, 56, 11), MODEL_ROV3: (3, 5, 5, 24, 7), MODEL_ROV6: (6, 9, 9, 41, 14)}
 # named planes of the SoA state returned by mvrl_get_state (first index / slice); integer planes are bit patterns
 STATE_PLANES = {
     MODEL_ROV6: dict(y=slice(0, 12), eold=slice(12, 18), eint=slice(18, 24), setpoint=slice(24, 30), path=slice(30, 36),
@@ -27,7 +27,7 @@ STATE_PLANES = {
     MODEL_ROV3: dict(y=slice(0, 6), eold=slice(6, 9), eint=slice(9, 12), setpoint=slice(12, 15), path=slice(15, 19),
                      episode=19, told=20, time=21, toffset=22, istep=23),
     MODEL_AUV: dict(pose=slice(0, 6), heading_target=6, herr_o=7, perr_o=slice(8, 10), mult=slice(10, 21), toffset=21,
-                    hist=slice(22, 52), istep=52, iwp=53, episode=54),
+                    hist=slice(22, 52), istep=52, iwp=53, episode=54, phase=55),
 }
 PREC_F32, PREC_F64 = 0, 1
 INTEG_RK4, INTEG_RK45 = 0, 1

@@ -42,8 +42,11 @@ typedef REAL real;
 /* Distance-to-discontinuity bookkeeping (tests only): while tl_margin points at a record, every RHS evaluation lowers
  * the record's entries to the smallest distance seen between the trajectory and a point where the reference's
  * right-hand side JUMPS (or, entry 4, amplifies rounding without bound):
- *   [0] |e - eOld| of a PID axis at a call with t - tOld <= 1e-9 (6DoF.py:64-66: dedt = +-(that)/1e-9 -> the demand sits
- *       on the +-umax rail given by the SIGN of a difference of two nearby errors); exact zeros (vehicle at rest) excluded
+ *   [0] |e - eOld| / (h * S) of a PID axis at a call with t - tOld <= 1e-9 (6DoF.py:64-66: dedt = +-(e - eOld)/1e-9 -> the
+ *       demand sits on the +-umax rail given by the SIGN of a difference of two nearby errors).  The difference is an
+ *       increment of the pose over (a fraction of) the sub-step h, i.e. h x a combination of pose rates sum_j J_ij nu_j;
+ *       S = sum_j |J_ij nu_j| is the size of the terms that rate is made of, so the ratio says how completely they
+ *       cancel - which is what another precision must reproduce to get the sign right.  Exact zeros (at rest) excluded
  *   [1] | |rpm| / deadband - 1 |  of a thruster after saturation (limit(), 6DoF.py:271-275: |rpm| < 300 -> 0)
  *   [2] | |e| - windup |  of an axis whose integral is non-zero (eInt[|e| > windup] = 0, 6DoF.py:68)
  *   [3] pi - |yaw error|  (angleError's branch at +-pi, resources.py:92-95)
@@ -52,6 +55,8 @@ typedef REAL real;
  * was within that precision's rounding of the quantity concerned. */
 #define ORC_N_MARGIN 5
 static __thread double* FN(tl_margin) = 0;
+static __thread double FN(tl_h) = 1.0;          /* sub-step of the RK4 harness */
+static __thread double FN(tl_rate)[6] = {1, 1, 1, 1, 1, 1};   /* S_i of the current RHS evaluation */
 static inline void margin_note(int k, double v) {
     double* m = FN(tl_margin);
     if (m && v < m[k]) m[k] = v;
@@ -138,7 +143,8 @@ static void pid_law(int n, const real* e, double t, pid_t_* s, const double* kp,
     real den = (real)(dtp > 1e-9 ? dtp : 1e-9);
     for (int i = 0; i < n; i++) {
         real dedt = (e[i] - s->eold[i]) / den;
-        if (dtp <= 1e-9 && e[i] != s->eold[i]) margin_note(0, (double)r_abs(e[i] - s->eold[i]));
+        if (dtp <= 1e-9 && e[i] != s->eold[i])
+            margin_note(0, (double)r_abs(e[i] - s->eold[i]) / (FN(tl_h) * (FN(tl_rate)[i] > 1e-12 ? FN(tl_rate)[i] : 1e-12)));
         s->eint[i] += (real)0.5 * (s->eold[i] + e[i]) * (real)dtp;
         if (s->eint[i] != 0) margin_note(2, (double)r_abs(r_abs(e[i]) - (real)windup[i]));
         if (r_abs(e[i]) > (real)windup[i]) s->eint[i] = 0;
@@ -270,6 +276,18 @@ void FN(orc_derivs6)(const mvrl_rov6_params* P, double t, const real y[12], cons
                      const real cur_glob[2], real dy[12], real gcf[6], real rpm[8]) {
     real axes[9];
     FN(orc_body_axes)(y + 3, axes);
+    if (FN(tl_margin)) {   /* size of the terms each pose rate is made of (margin [0]) */
+        real J[36];
+        double* save = FN(tl_margin);
+        FN(tl_margin) = 0;
+        FN(orc_coord_transform6)(y[3], y[4], y[5], J);
+        FN(tl_margin) = save;
+        for (int i = 0; i < 6; i++) {
+            double sabs = 0;
+            for (int j = 0; j < 6; j++) sabs += (double)r_abs(J[6 * i + j] * y[6 + j]);
+            FN(tl_rate)[i] = sabs;
+        }
+    }
     FN(orc_pid6)(P, sp, y, t, pid, gcf);
     FN(orc_alloc6)(P, axes, gcf, rpm);
     rhs6_given_rpm(P, y, axes, rpm, cur_glob, dy);
@@ -282,6 +300,12 @@ static void ctrl3(const mvrl_rov3_params* P, double t, const real y[6], const re
     real psi = y[2];
     real e[3] = {sp[0] - y[0], sp[1] - y[1], FN(orc_angle_error)(sp[2], psi)};
     margin_note(3, 3.14159265358979323846 - (double)r_abs(e[2]));
+    if (FN(tl_margin)) {   /* eta_dot = J(psi) nu (3DoF.py:288): sizes of the terms of each pose rate (margin [0]) */
+        double cp = fabs((double)r_cos(psi)), sn = fabs((double)r_sin(psi));
+        FN(tl_rate)[0] = cp * fabs((double)y[3]) + sn * fabs((double)y[4]);
+        FN(tl_rate)[1] = sn * fabs((double)y[3]) + cp * fabs((double)y[4]);
+        FN(tl_rate)[2] = fabs((double)y[5]);
+    }
     real cvv[3];
     pid_law(3, e, t, pid, P->kp, P->ki, P->kd, P->windup, P->umax, cvv);
     real c = r_cos(psi), s = r_sin(psi);
@@ -402,6 +426,7 @@ static void integrate_rk4(rhs_ctx* c, double t0, double dt, int n_sub, real* y) 
     int n = 2 * c->dof;
     double h = dt / n_sub;
     real hh = (real)h;
+    FN(tl_h) = h;
     real k1[12], k2[12], k3[12], k4[12], yt[12];
     for (int k = 0; k < n_sub; k++) {
         double tk = t0 + k * h;

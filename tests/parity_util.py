@@ -11,18 +11,17 @@ one of them at some step <= s.  Envs beyond tolerance WITHOUT such an approach f
 """
 import numpy as np
 
-# fp32 bounds, in the units of oracle.OracleRovEnv.margins.  Calibrated on 6 x 4096 envs x 25 steps (tools/margin_probe.py,
+# fp32 bounds, in the units of oracle.OracleRovEnv.margins.  Calibrated on 6 x 16384 envs x 60 steps (tools/margin_probe.py,
 # gpurun_out/r2_margins*.log): the largest distance seen on an env that jumped off x ~3.
 F32_BOUNDS = np.array([
-    6e-8,    # |e - eOld| at a zero-dt PID call [m or rad]: the increment is h/2 x (pose rate); the rate's fp32 error is ~1e-7 x |terms|
+    3e-5,    # |e - eOld| / (h x sum_j |J_ij nu_j|) at a zero-dt PID call: how completely the terms of a pose rate cancel; fp32
+             # carries each term to 6e-8 and the increment is a difference of two or four stage slopes
     3e-4,    # | |rpm| / 300 - 1 |: the dead-band acts on demands of O(1..40 N) whose fp32 error is ~1e-6 x the terms of Ainv b
     1e-4,    # | |e| - windup | [m or rad]
     1e-4,    # pi - |yaw error| [rad]
     5e-2,    # |cos(theta)|: 1 / cos(theta) amplifies fp32 rounding 20 x and more
 ])
-# 3-DoF: yaw inertia 0.28 kg m^2 against 100 N m of yaw demand -> yaw rates of tens of rad/s, whose fp32 rounding enters every
-# pose rate through J(psi): jumps were seen at increments up to 1.9e-7 (16384 envs x 60 steps)
-F32_BOUNDS_3DOF = F32_BOUNDS * np.array([5.0, 1, 1, 1, 1])
+F32_BOUNDS_3DOF = F32_BOUNDS
 
 
 def bounds_for(dof):

@@ -1,22 +1,27 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun) from the repo root: kernel-trace stats + HBM traffic counters of the bench command.
-#   bash tools/profile_round.sh <workload> <tag>
-# Pass 1 (--kernel-trace --stats) profiles the SAME command the bench line comes from (default steps / warm-up);
-# the two counter passes (FETCH_SIZE, WRITE_SIZE - separately, as MI355X_MICROARCH.md prescribes) only need per-launch
-# byte counts, so they run 300 steps.  Raw output lands under gpurun_out/prof_<tag>_*; tools/summarize_profile.py
-# condenses it into profiles/.
-set -e
+# Run on the GPU box (via gpurun) from the repo root: the rocprofv3 evidence behind bench.py's roofline objects.
+#   bash tools/profile_round.sh <workload> <tag> [extra bench args]
+# Pass 1 (--kernel-trace --stats) profiles the SAME command the bench line comes from (defaults: chains, repeats, K).
+# The counter passes (one rocprofv3 run per group, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE separately)
+# need per-launch values only: 200 steps, one launch per step (--chains 1), so that one dispatch = one env step of the batch.
+# Raw output lands under gpurun_out/prof_<tag>_*; tools/summarize_counters.py condenses it into profiles/.
 WL=${1:-c4}
-TAG=${2:-r01_$WL}
+TAG=${2:-r02_$WL}
+shift 2
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --workload $WL --no-cpu-baseline $EXTRA"
-PMC_ARGS="$ARGS --steps 300 --warmup 30"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_kt -- python3 $ARGS > $OUT/prof_${TAG}_kt.json 2> $OUT/prof_${TAG}_kt.err
-# the per-dispatch trace of a 5500-launch run is large: keep the stats tables only
-find $OUT/prof_${TAG}_kt -name "*_kernel_trace.csv" -delete
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_fetch -- python3 $PMC_ARGS > $OUT/prof_${TAG}_fetch.json 2> $OUT/prof_${TAG}_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}_write -- python3 $PMC_ARGS > $OUT/prof_${TAG}_write.json 2> $OUT/prof_${TAG}_write.err
-find $OUT/prof_${TAG}_fetch $OUT/prof_${TAG}_write -name "*_kernel_trace.csv" -delete
-tail -c 600 $OUT/prof_${TAG}_kt.json
+ARGS="$ROOT/bench.py --workload $WL --no-cpu-baseline $*"
+PMC_ARGS="$ARGS --chains 1 --steps 200 --warmup 20 --repeats 1 --prewarm-s 0.2"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_kt -- python3 $ARGS > $OUT/prof_${TAG}_kt.json 2> $OUT/prof_${TAG}_kt.err
+rc=$?; echo "kt rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
+find $OUT/prof_${TAG}_kt -name "*_kernel_trace.csv" -delete     # the per-dispatch trace of a 10k-launch run is large: keep the stats tables
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 240 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/prof_${TAG}_pmc$i -- python3 $PMC_ARGS > $OUT/prof_${TAG}_pmc$i.json 2> $OUT/prof_${TAG}_pmc$i.err
+  rc=$?; echo "pmc group $i ($grp) rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
+  find $OUT/prof_${TAG}_pmc$i -name "*_kernel_trace.csv" > $OUT/prof_${TAG}_pmc$i.tracefiles
+done
+tail -c 400 $OUT/prof_${TAG}_kt.json

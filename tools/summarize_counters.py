@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Condense the raw rocprofv3 output of tools/profile_round.sh (gpurun_out/prof_<tag>_{kt,pmc*}) into the tracked summaries:
+
+   profiles/<tag>_kernel_stats.csv   the --kernel-trace --stats table of the bench command (top rows)
+   profiles/r02_counters.json        per workload: HBM bytes per env step (FETCH_SIZE / WRITE_SIZE), VALU instruction counts,
+                                     wave cycles, effective clock - keyed by the kernel-source hash bench.py checks
+
+    python tools/summarize_counters.py <tag> <workload> <kernel substring> <n_envs> <algorithmic read B> <algorithmic B>
+
+Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE come from SEPARATE passes, are in
+KiB, WRITE_SIZE is exact, and on gfx950 FETCH_SIZE under-reports streaming reads by 2x (calibrated in round 1 on the no-flow
+6-DoF kernel, whose reads are exactly 152 B per env: profiles/r01_pmc_traffic.json "calibration").  SQ_WAVE_CYCLES /
+SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs.
+"""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "gpurun_out")
+PROF = os.path.join(REPO, "profiles")
+
+
+def counters(tag, kernel_substr):
+    acc, dur = {}, []
+    for d in sorted(glob.glob(os.path.join(OUT, f"prof_{tag}_pmc*"))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if kernel_substr in r["Kernel_Name"]:
+                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                    if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                        dur.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}, (sum(dur) / len(dur) if dur else None)
+
+
+def main():
+    tag, wl, kernel_substr, n_envs, alg_read, alg_bytes = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5]), float(sys.argv[6])
+    from marinevehiclereinforcementlearning_amd import build
+    os.makedirs(PROF, exist_ok=True)
+    ks = glob.glob(os.path.join(OUT, f"prof_{tag}_kt", "*", "*_kernel_stats.csv"))
+    avg_ns = calls = None
+    if ks:
+        rows = list(csv.reader(open(ks[0])))
+        with open(os.path.join(PROF, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            for r in rows[:8]:
+                w.writerow([c[:160] for c in r])
+        for r in rows[1:]:
+            if kernel_substr in r[0]:
+                calls, avg_ns = int(r[1]), float(r[3])
+                break
+    c, cnt, dur_ns = counters(tag, kernel_substr)
+    waves = c.get("SQ_WAVES") or (n_envs / 64.0)
+    ent = {"tag": tag, "kernel": kernel_substr, "envs": n_envs, "launches_averaged": cnt,
+           "bench_command_kernel_avg_us": None if avg_ns is None else avg_ns / 1e3, "bench_command_kernel_calls": calls,
+           "counter_pass_launch": "one launch per env step (--chains 1), 200 steps", "raw": c,
+           "algorithmic_read_bytes_per_env": alg_read, "algorithmic_bytes_per_env": alg_bytes}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        rd, wr = 2.0 * c["FETCH_SIZE"] * 1024.0, c["WRITE_SIZE"] * 1024.0
+        ent.update({"fetch_correction": 2.0, "hbm_read_bytes_per_step": rd, "hbm_write_bytes_per_step": wr,
+                    "hbm_bytes_per_step": rd + wr, "hbm_bytes_per_env": (rd + wr) / n_envs,
+                    "hbm_read_bytes_per_env": rd / n_envs, "hbm_write_bytes_per_env": wr / n_envs})
+    if "SQ_INSTS_VALU" in c:
+        v = {"wave_instr_per_env_step": c["SQ_INSTS_VALU"] / waves,
+             "note": "SQ_INSTS_VALU / SQ_WAVES: VALU instructions the wave that owns an env executes per env step"}
+        if "SQ_INSTS_VALU_FMA_F32" in c:
+            v["flops_per_env_step"] = (2 * c["SQ_INSTS_VALU_FMA_F32"] + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c.get("SQ_INSTS_VALU_ADD_F32", 0)
+                                       + c.get("SQ_INSTS_VALU_TRANS_F32", 0)) / waves
+        if "SQ_WAVE_CYCLES" in c:
+            v["wave_cycles_per_wave"] = 4.0 * c["SQ_WAVE_CYCLES"] / waves
+            v["valu_active_cycles_per_wave"] = 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0) / waves
+            v["wait_inst_cycles_per_wave"] = 4.0 * c.get("SQ_WAIT_INST_ANY", 0) / waves
+            v["wait_mem_cycles_per_wave"] = 4.0 * c.get("SQ_WAIT_ANY", 0) / waves
+        if "GRBM_GUI_ACTIVE" in c and dur_ns:
+            v["effective_clock_GHz_under_profiler"] = c["GRBM_GUI_ACTIVE"] / 8.0 / dur_ns
+            v["kernel_us_under_profiler"] = dur_ns / 1e3
+        ent["valu"] = v
+    path = os.path.join(PROF, "r02_counters.json")
+    data = json.load(open(path)) if os.path.exists(path) else {"workloads": {}}
+    data["kernel_source_hash"] = build.source_hash()
+    try:
+        data["commit"] = subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:  # noqa: BLE001
+        data["commit"] = None
+    data["workloads"][wl] = ent
+    json.dump(data, open(path, "w"), indent=1)
+    print(json.dumps({k: ent[k] for k in ent if k != "raw"}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,7 @@ VARIANTS = {
     "auvskip2": dict(extra=["-DMVRL_AUV_SKIP=2"], drop=()),  #   no observation stores
     "auvskip4": dict(extra=["-DMVRL_AUV_SKIP=4"], drop=()),  #   no reward / done stores
     "auvskip8": dict(extra=["-DMVRL_AUV_SKIP=8"], drop=()),  #   no pose / error-memory stores
+    "trigwave": dict(extra=["-DMVRL_TRIG_WAVE_FALLBACK"], drop=()),   # a wave with one large angle increment evaluates the stage in full for all lanes
     "w2": dict(extra=["-DMVRL_MIN_WAVES=2"], drop=()),
     "w3": dict(extra=["-DMVRL_MIN_WAVES=3"], drop=()),
     "w4": dict(extra=["-DMVRL_MIN_WAVES=4"], drop=()),                # spills
