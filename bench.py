@@ -303,6 +303,7 @@ def main():
             t0 = time.perf_counter()
             for ev, st_ in zip(e0, stepper.streams):
                 ev.record(st_)
+            stepper.arm()        # first launches staggered: the chains' tails must not coincide (a K = 20 region is too short to drift apart)
             run_plain(K)
             for ev, st_ in zip(e1, stepper.streams):
                 ev.record(st_)
@@ -329,6 +330,22 @@ def main():
     order = sorted(range(len(reps)), key=lambda i: reps[i]["elapsed"])
     med = reps[order[len(order) // 2]]
     elapsed, kern_ms, launches = med["elapsed"], med["kern_ms"], med["launches"]
+
+    # The same workload as ONE launch per step on one stream, three short repeats: the figure that compares one-to-one with
+    # rocprofv3's per-kernel average (profiles/r02_*_chains1_kernel_stats.csv).  With chains, launches overlap in time: each
+    # half-batch launch lasts about as long as a whole step, two being in flight at any moment.
+    single = None
+    if stepper is not None:
+        ks = []
+        for r in range(3):
+            sync()
+            h.timing_begin(stream)
+            for k in range(K):
+                env.step_tensors(ring[k % RING])
+            ms, nl = h.timing_end(stream)
+            sync()
+            ks.append(ms * 1e3 / max(1, nl))
+        single = sorted(ks)[1]
 
     obs_t, _, _ = env._ensure_tensors()
     finite = bool(torch.isfinite(obs_t).all().item())
@@ -391,6 +408,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_us_per_step": per_step_s * 1e6, "kernel_launches_per_step": launches / max(1e-9, steps_per_region),
                          "algorithmic_bytes_per_env_step": wl["bytes"], "valu": valu, "kernel_source_hash": khash,
+                         "single_launch": None if single is None else {
+                             "kernel_us_per_launch": single, "achieved": wl["bytes"] * n / (single * 1e-6) / 1e9,
+                             "frac": wl["bytes"] * n / (single * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "note": "one launch per step on one stream (--chains 1), median of 3 x K launches by HIP events: "
+                                     "compare with rocprofv3's per-kernel average of the --chains 1 profile"},
                          "note": ("fused episodes: the bytes are the turbulence gathers (L2 / Infinity-Cache resident), the kernel is "
                                   "bound by instruction issue, not HBM" if pd_obj is not None else
                                   "HBM-bound kernel" if wl["model"].startswith("auv") else

@@ -45,6 +45,12 @@ class ChainStepper:
             s.wait_stream(cur)
         self._armed = self.stagger
 
+    def arm(self):
+        """Stagger the next step without a fork (the caller has synchronised the device itself): chains that start in the same
+        instant also end together - their launch gaps and tails coincide and nothing overlaps them until the chains have
+        drifted apart, which takes tens of steps."""
+        self._armed = self.stagger
+
     def step(self, actions, out=None):
         env = self.env
         rt = torch.float64 if env.handle.f64 else torch.float32

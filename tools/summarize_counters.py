@@ -55,10 +55,25 @@ def main():
             if kernel_substr in r[0]:
                 calls, avg_ns = int(r[1]), float(r[3])
                 break
+    avg1_ns = calls1 = None
+    ks1 = glob.glob(os.path.join(OUT, f"prof_{tag}_kt1", "*", "*_kernel_stats.csv"))
+    if ks1:
+        rows = list(csv.reader(open(ks1[0])))
+        with open(os.path.join(PROF, f"{tag}_chains1_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            for r in rows[:8]:
+                w.writerow([c_[:160] for c_ in r])
+        for r in rows[1:]:
+            if kernel_substr in r[0]:
+                calls1, avg1_ns = int(r[1]), float(r[3])
+                break
     c, cnt, dur_ns = counters(tag, kernel_substr)
     waves = c.get("SQ_WAVES") or (n_envs / 64.0)
     ent = {"tag": tag, "kernel": kernel_substr, "envs": n_envs, "launches_averaged": cnt,
            "bench_command_kernel_avg_us": None if avg_ns is None else avg_ns / 1e3, "bench_command_kernel_calls": calls,
+           "bench_command_note": "default bench: 2 chains, each launch covers half the batch and two launches are in flight at any time, "
+                                 "so a launch lasts about one whole step",
+           "chains1_kernel_avg_us": None if avg1_ns is None else avg1_ns / 1e3, "chains1_kernel_calls": calls1,
            "counter_pass_launch": "one launch per env step (--chains 1), 200 steps", "raw": c,
            "algorithmic_read_bytes_per_env": alg_read, "algorithmic_bytes_per_env": alg_bytes}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
