@@ -104,10 +104,11 @@ def main():
     # run measures 145 us/launch, 2000 steps and more 133 us on the same device)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is repeated this many times; the median is reported")
+    ap.add_argument("--repeats", type=int, default=11, help="the K-step timed region is repeated this many times; the median is reported "
+                    "(short regions swing by +-4 % with the power controller's state: see timing.ms_per_step_repeats)")
     ap.add_argument("--prewarm-s", type=float, default=0.4, help="seconds of untimed steps before the warm-up (clock settling)")
     ap.add_argument("--chains", type=int, default=2, help="independent lane-range chains per step (1 = one launch per step on one stream)")
-    ap.add_argument("--no-stagger", action="store_true", help="do not offset the chains' first launches")
+    ap.add_argument("--no-stagger", action="store_true", help="do not phase the chains against each other at the start of a timed region")
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
     ap.add_argument("--rollout", action="store_true", help="step through mvrl_rollout_dev: the RING action batches per call "
@@ -201,7 +202,10 @@ def main():
         EP = 250
         pd_steps = torch.zeros((), dtype=torch.int64, device=dev)     # env steps actually taken (episodes may end early)
 
-    use_chains = (args.chains > 1 and loop_objs is None and pd_obj is None and not args.rollout and not args.graph)
+    # chains pay when a launch fills the chip several times over (C4: 16 waves per SIMD); a batch of one wave per SIMD
+    # (C2: 65 536 envs) is latency-bound and only gets slower when it is cut in two
+    use_chains = (args.chains > 1 and loop_objs is None and pd_obj is None and not args.rollout and not args.graph
+                  and (n // 64) >= 4 * N_SIMD)
     stepper = None
     if use_chains:
         from marinevehiclereinforcementlearning_amd.chains import ChainStepper
@@ -287,6 +291,7 @@ def main():
         if time.perf_counter() - t_pre >= args.prewarm_s:
             break
     prewarm_s = time.perf_counter() - t_pre
+    step_us_estimate = prewarm_s / max(1, pre_steps) * 1e6      # what a step takes on this device, for the chains' phase offset
     run_plain(W)
     sync()
     reps = []
@@ -303,7 +308,7 @@ def main():
             t0 = time.perf_counter()
             for ev, st_ in zip(e0, stepper.streams):
                 ev.record(st_)
-            stepper.arm()        # first launches staggered: the chains' tails must not coincide (a K = 20 region is too short to drift apart)
+            stepper.phase_delay(step_us_estimate)   # chain c starts c/C of a step late: tails and launch gaps never coincide
             run_plain(K)
             for ev, st_ in zip(e1, stepper.streams):
                 ev.record(st_)
@@ -350,6 +355,7 @@ def main():
     obs_t, _, _ = env._ensure_tensors()
     finite = bool(torch.isfinite(obs_t).all().item())
 
+    rccl = D.rccl_info(backend, local_rank) if world > 1 else None    # a collective: every rank takes part
     out = None
     if rank == 0:
         value = world * n * K / elapsed
@@ -387,7 +393,7 @@ def main():
                        "mvrl_rollout_dev: %d env steps per call" % RING if roll_out is not None else
                        "hip graph of %d steps" % RING if graph is not None else
                        "%d chains of lane ranges on %d streams (mvrl_step_range_dev), %d launches per step%s" %
-                       (stepper.n_chains, stepper.n_chains, stepper.n_chains, "" if args.no_stagger else ", first launches staggered")
+                       (stepper.n_chains, stepper.n_chains, stepper.n_chains, "" if args.no_stagger else ", chain c starts c/C of a step late (mvrl_delay_dev)")
                        if stepper is not None else "one launch per step")
         out = {
             "metric": "env-steps/sec (whole node) + achieved HBM GB/s, 6-DoF batch", "value": value, "unit": "env-steps/s",
@@ -422,7 +428,7 @@ def main():
             "outputs_finite": finite,
         }
         if world > 1:
-            out["rccl"] = D.rccl_info(backend, local_rank)
+            out["rccl"] = rccl
 
     if gather is not None:
         # The same K steps with BASELINE configs[4]'s exchange: every rank's (obs, reward, done) message gathered to

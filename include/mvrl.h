@@ -333,6 +333,9 @@ int mvrl_fill_uniform_dev(mvrl_handle* h, float* dst_dev, int64_t n, uint64_t se
 /* HIP-event timing of step kernels launched through mvrl_step_dev on `stream`:
  * begin records an event, end records another, synchronises it and returns elapsed ms and launch count. */
 int mvrl_timing_begin(mvrl_handle* h, void* stream);
+/* Occupy `stream` for about `microseconds` (<= 10 000) with a single idle wave: phases independent chains of lane ranges
+ * against each other without a cross-stream dependency (chains.ChainStepper.phase_delay). */
+int mvrl_delay_dev(mvrl_handle* h, int32_t microseconds, void* stream);
 /* step-kernel launches (env steps x lane ranges) enqueued through this handle since mvrl_create */
 int mvrl_launch_count(mvrl_handle* h, int64_t* n_launches);
 int mvrl_timing_end(mvrl_handle* h, void* stream, float* elapsed_ms, int64_t* n_launches);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "mvrl_create", "mvrl_destroy", "mvrl_set_flow", "mvrl_set_flow_dev", "mvrl_reset", "mvrl_reset_dev", "mvrl_step",
     "mvrl_step_async", "mvrl_step_wait", "mvrl_step_dev", "mvrl_step_range_dev", "mvrl_get_terminal_obs", "mvrl_get_terminal_obs_dev",
     "mvrl_get_state", "mvrl_set_state", "mvrl_enable_aux", "mvrl_get_aux", "mvrl_flow_interp", "mvrl_flow_reconstruct",
-    "mvrl_fill_uniform_dev", "mvrl_timing_begin", "mvrl_timing_end", "mvrl_launch_count", "mvrl_dev_alloc", "mvrl_dev_free",
+    "mvrl_fill_uniform_dev", "mvrl_timing_begin", "mvrl_timing_end", "mvrl_launch_count", "mvrl_delay_dev", "mvrl_dev_alloc", "mvrl_dev_free",
     "mvrl_dev_upload", "mvrl_dev_download", "mvrl_synchronize",
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
@@ -87,6 +87,7 @@ def load(path=None):
     lib.mvrl_fill_uniform_dev.argtypes = [vp, vp, i64, u64, u64, fp, fp, vp]
     lib.mvrl_timing_begin.argtypes = [vp, vp]
     lib.mvrl_launch_count.argtypes = [vp, C.POINTER(i64)]
+    lib.mvrl_delay_dev.argtypes = [vp, i32, vp]
     lib.mvrl_timing_end.argtypes = [vp, vp, C.POINTER(fp), C.POINTER(i64)]
     lib.mvrl_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.mvrl_dev_free.argtypes = [vp, vp]
@@ -313,6 +314,9 @@ class Handle:
         """Step launches replayed from a captured graph do not pass through the library: account for them here so
         that timing_end() reports the right launch count."""
         self._graph_launches = getattr(self, "_graph_launches", 0) + int(k)
+
+    def delay_dev(self, microseconds, stream=None):
+        check(self.lib.mvrl_delay_dev(self.h, int(microseconds), stream), self.h)
 
     def launch_count(self):
         nl = C.c_int64()

@@ -51,6 +51,17 @@ class ChainStepper:
         drifted apart, which takes tens of steps."""
         self._armed = self.stagger
 
+    def phase_delay(self, step_us):
+        """Start chain c about c / n_chains of a step late, WITHOUT a cross-stream dependency: a one-wave kernel that spins for
+        that long is queued on the chain's stream ahead of its next launch (mvrl_delay_dev).  Chains that start in the same
+        instant also end in the same instant, launch after launch, until they happen to drift apart (tens of steps); with
+        the offset the second chain's kernel covers the first chain's launch gap and tail from the first step on.  Call it
+        with every stream idle (e.g. after a device synchronise) and a rough step time in microseconds."""
+        if not self.stagger or step_us <= 0:
+            return
+        for c in range(1, self.n_chains):
+            self.env.handle.delay_dev(int(step_us * c / self.n_chains), self.streams[c].cuda_stream)
+
     def step(self, actions, out=None):
         env = self.env
         rt = torch.float64 if env.handle.f64 else torch.float32

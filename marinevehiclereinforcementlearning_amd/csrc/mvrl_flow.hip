@@ -90,6 +90,21 @@ hipError_t launch_flow_reconstruct(const float* modes_re, const float* modes_im,
     return hipGetLastError();
 }
 
+// One idle wave that holds its stream for `ticks` ticks of the 100 MHz real-time counter (mvrl_delay_dev).  Exit is
+// guaranteed: the loop ends after a bounded number of polls whatever the counter does.
+__global__ __launch_bounds__(64) void delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int guard = 0; guard < (1 << 22); guard++) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+hipError_t launch_delay(int microseconds, hipStream_t stream) {
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long)microseconds * 100ull);
+    return hipGetLastError();
+}
+
 hipError_t launch_fill_uniform(float* dst, int64_t n, uint64_t seed, uint64_t counter, float lo, float hi,
                                hipStream_t stream) {
     int64_t nq = (n + 3) / 4;

@@ -98,7 +98,15 @@ def main():
         ent["valu"] = v
     path = os.path.join(PROF, "r02_counters.json")
     data = json.load(open(path)) if os.path.exists(path) else {"workloads": {}}
-    data["kernel_source_hash"] = build.source_hash()
+    # identity of the build that was PROFILED: the bench line printed under the profiler carries it
+    khash = None
+    try:
+        khash = json.loads(open(os.path.join(OUT, f"prof_{tag}_kt.json")).read().strip().splitlines()[-1])["roofline"]["kernel_source_hash"]
+    except Exception:  # noqa: BLE001
+        pass
+    if data.get("kernel_source_hash") not in (None, khash):
+        data["workloads"] = {}                       # summaries of an older build do not mix with this one
+    data["kernel_source_hash"] = khash or build.source_hash()
     try:
         data["commit"] = subprocess.run(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:  # noqa: BLE001
