@@ -108,6 +108,8 @@ def main():
                     "(short regions swing by +-4 % with the power controller's state: see timing.ms_per_step_repeats)")
     ap.add_argument("--prewarm-s", type=float, default=0.4, help="seconds of untimed steps before the warm-up (clock settling)")
     ap.add_argument("--chains", type=int, default=2, help="independent lane-range chains per step (1 = one launch per step on one stream)")
+    ap.add_argument("--launch", default="auto", choices=["auto", "chains", "single"],
+                    help="per-step launch plan: C chains of lane ranges, one launch per step, or (auto) time both and report the faster")
     ap.add_argument("--no-stagger", action="store_true", help="do not phase the chains against each other at the start of a timed region")
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=0)
@@ -294,12 +296,13 @@ def main():
     step_us_estimate = prewarm_s / max(1, pre_steps) * 1e6      # what a step takes on this device, for the chains' phase offset
     run_plain(W)
     sync()
-    reps = []
-    for r in range(max(1, args.repeats)):
+    def timed_region(plan):
+        """K steps between barrier + synchronize pairs under one launch plan; returns wall time (max over ranks), GPU time by
+        HIP events on the launching stream(s), and the number of kernel launches."""
         if pd_obj is not None:
             pd_steps.zero_()
         sync()
-        if stepper is not None:
+        if plan == "chains":
             # HIP events on the streams the kernels are launched on: one pair per chain; the region's GPU time is the span
             # from the earliest begin event to the latest end event
             e0 = [torch.cuda.Event(enable_timing=True) for _ in stepper.streams]
@@ -309,7 +312,8 @@ def main():
             for ev, st_ in zip(e0, stepper.streams):
                 ev.record(st_)
             stepper.phase_delay(step_us_estimate)   # chain c starts c/C of a step late: tails and launch gaps never coincide
-            run_plain(K)
+            for k in range(K):
+                stepper.step(ring[k % RING])
             for ev, st_ in zip(e1, stepper.streams):
                 ev.record(st_)
             sync()
@@ -319,7 +323,11 @@ def main():
         else:
             h.timing_begin(stream)
             t0 = time.perf_counter()
-            run_plain(K)
+            if plan == "single":
+                for k in range(K):
+                    env.step_tensors(ring[k % RING])
+            else:
+                run_plain(K)
             kern_ms, launches = h.timing_end(stream)
             sync()
             elapsed = time.perf_counter() - t0
@@ -331,26 +339,34 @@ def main():
             if world > 1:
                 dist.all_reduce(pd_steps)          # whole-job env steps
             psteps = float(pd_steps.item())
-        reps.append(dict(elapsed=float(t.item()), kern_ms=kern_ms, launches=launches, pd_steps=psteps))
-    order = sorted(range(len(reps)), key=lambda i: reps[i]["elapsed"])
-    med = reps[order[len(order) // 2]]
-    elapsed, kern_ms, launches = med["elapsed"], med["kern_ms"], med["launches"]
+        return dict(elapsed=float(t.item()), kern_ms=kern_ms, launches=launches, pd_steps=psteps)
 
-    # The same workload as ONE launch per step on one stream, three short repeats: the figure that compares one-to-one with
-    # rocprofv3's per-kernel average (profiles/r02_*_chains1_kernel_stats.csv).  With chains, launches overlap in time: each
-    # half-batch launch lasts about as long as a whole step, two being in flight at any moment.
-    single = None
+    # Launch plans for the per-step path: "chains" (C lane ranges on C streams) and "single" (one launch per step).  Chains
+    # win once a region is long enough for their pipeline to matter (K in the hundreds: -8 %); in a 2-ms region the half-step
+    # phase offset they start with costs what they gain.  With --launch auto both plans are timed, ALTERNATING repeat by
+    # repeat so that they see the same power-controller state, and the faster median is the headline; both are in the line.
+    plans = ["default"]
     if stepper is not None:
-        ks = []
-        for r in range(3):
-            sync()
-            h.timing_begin(stream)
-            for k in range(K):
-                env.step_tensors(ring[k % RING])
-            ms, nl = h.timing_end(stream)
-            sync()
-            ks.append(ms * 1e3 / max(1, nl))
-        single = sorted(ks)[1]
+        plans = {"auto": ["chains", "single"], "chains": ["chains"], "single": ["single"]}[args.launch]
+    by_plan = {pl: [] for pl in plans}
+    for r in range(max(1, args.repeats)):
+        for pl in plans:
+            by_plan[pl].append(timed_region(pl))
+
+    def median_of(lst):
+        order = sorted(range(len(lst)), key=lambda i: lst[i]["elapsed"])
+        return lst[order[len(order) // 2]]
+    meds = {pl: median_of(v) for pl, v in by_plan.items()}
+    plan = min(meds, key=lambda pl: meds[pl]["elapsed"])       # identical on every rank: the times are all-reduced
+    reps, med = by_plan[plan], meds[plan]
+    elapsed, kern_ms, launches = med["elapsed"], med["kern_ms"], med["launches"]
+    single = None
+    if "single" in meds:
+        single = meds["single"]["kern_ms"] * 1e3 / max(1, meds["single"]["launches"])
+    if plan == "single":
+        stepper_used = None
+    else:
+        stepper_used = stepper
 
     obs_t, _, _ = env._ensure_tensors()
     finite = bool(torch.isfinite(obs_t).all().item())
@@ -394,13 +410,18 @@ def main():
                        "hip graph of %d steps" % RING if graph is not None else
                        "%d chains of lane ranges on %d streams (mvrl_step_range_dev), %d launches per step%s" %
                        (stepper.n_chains, stepper.n_chains, stepper.n_chains, "" if args.no_stagger else ", chain c starts c/C of a step late (mvrl_delay_dev)")
-                       if stepper is not None else "one launch per step")
+                       if stepper_used is not None else "one launch per step")
+        if len(plans) > 1:
+            launch_desc += "; chosen by measurement among " + ", ".join(
+                "%s %.1f us/step" % (pl, meds[pl]["elapsed"] / K * 1e6) for pl in plans)
         out = {
             "metric": "env-steps/sec (whole node) + achieved HBM GB/s, 6-DoF batch", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "timing": {"repeats": len(reps), "statistic": "median repeat of the K-step region (max over ranks per repeat)",
                        "ms_per_step_repeats": [r_["elapsed"] / K * 1e3 for r_ in reps],
+                       "launch_plans": {pl: {"ms_per_step": meds[pl]["elapsed"] / K * 1e3,
+                                             "ms_per_step_repeats": [r_["elapsed"] / K * 1e3 for r_ in by_plan[pl]]} for pl in plans},
                        "prewarm_s": prewarm_s, "prewarm_steps": pre_steps},
             "config": {"workload": wl["name"], "envs_per_gpu": n, "global_envs": world * n, "dt": 0.02 if wl["model"].startswith("auv") else 0.2,
                        "n_substeps": args.n_substeps, "control_mode": args.control_mode, "episode_len": 250,
@@ -417,7 +438,7 @@ def main():
                          "single_launch": None if single is None else {
                              "kernel_us_per_launch": single, "achieved": wl["bytes"] * n / (single * 1e-6) / 1e9,
                              "frac": wl["bytes"] * n / (single * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                             "note": "one launch per step on one stream (--chains 1), median of 3 x K launches by HIP events: "
+                             "note": "the `single` launch plan (one launch per step on one stream), median region by HIP events: "
                                      "compare with rocprofv3's per-kernel average of the --chains 1 profile"},
                          "note": ("fused episodes: the bytes are the turbulence gathers (L2 / Infinity-Cache resident), the kernel is "
                                   "bound by instruction issue, not HBM" if pd_obj is not None else

@@ -86,3 +86,30 @@ def test_host_call_after_chains_waits_for_every_stream():
     cnt = e.handle.step_counter()          # no explicit synchronisation
     assert (cnt == 20).all()
     e.close()
+
+
+def test_delay_kernel_holds_its_stream_and_always_ends():
+    """mvrl_delay_dev: one idle wave that occupies a stream for about the requested time (used to phase chains against each
+    other without a cross-stream dependency); out-of-range requests are refused; work queued behind it on the same stream
+    starts late, work on another stream does not wait."""
+    import time
+    import torch
+    h = _lib.Handle(P.make_config("rov6", 64, auto_reset=False, max_steps=10))
+    with pytest.raises(_lib.MvrlError):
+        h.delay_dev(10001, None)
+    with pytest.raises(_lib.MvrlError):
+        h.delay_dev(-1, None)
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    e0, e1, f0, f1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+    h.delay_dev(200, s0.cuda_stream)                     # warm-up (first launch of the kernel)
+    torch.cuda.synchronize()
+    e0.record(s0); f0.record(s1)
+    h.delay_dev(3000, s0.cuda_stream)
+    e1.record(s0); f1.record(s1)
+    t0 = time.perf_counter()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 1.0                # it ended
+    assert 2.5 < e0.elapsed_time(e1) < 6.0               # ms: the stream was held for about 3 ms
+    assert f0.elapsed_time(f1) < 1.0                     # the other stream did not wait
+    h.delay_dev(0, s0.cuda_stream)                       # no-op
+    h.close()

@@ -15,7 +15,9 @@ except Exception as e:
 PY
 }
 run --workload c4
+run --workload c4 --launch chains
 run --workload c4 --chains 1
+run --workload c4 --steps 20 --warmup 5
 run --workload c4 --control-mode zoh
 run --workload c4 --n-substeps 8
 run --workload c4 --precision f64 --steps 400 --warmup 40

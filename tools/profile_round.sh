@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun) from the repo root: the rocprofv3 evidence behind bench.py's roofline objects.
 #   bash tools/profile_round.sh <workload> <tag> [extra bench args]
-# Pass 1 (--kernel-trace --stats) profiles the SAME command the bench line comes from (defaults: chains, repeats, K).
+# Pass 1 (--kernel-trace --stats) profiles the bench command under its `chains` launch plan (defaults: repeats, K), pass 1b
+# under the `single` plan (--chains 1); bench.py's default (--launch auto) times both plans and reports the faster.
 # The counter passes (one rocprofv3 run per group, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE separately)
 # need per-launch values only: 200 steps, one launch per step (--chains 1), so that one dispatch = one env step of the batch.
 # Raw output lands under gpurun_out/prof_<tag>_*; tools/summarize_counters.py condenses it into profiles/.
@@ -13,7 +14,7 @@ OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --workload $WL --no-cpu-baseline $*"
 PMC_ARGS="$ARGS --chains 1 --steps 200 --warmup 20 --repeats 1 --prewarm-s 0.2"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_kt -- python3 $ARGS > $OUT/prof_${TAG}_kt.json 2> $OUT/prof_${TAG}_kt.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_kt -- python3 $ARGS --launch chains > $OUT/prof_${TAG}_kt.json 2> $OUT/prof_${TAG}_kt.err
 rc=$?; echo "kt rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
 find $OUT/prof_${TAG}_kt -name "*_kernel_trace.csv" -delete     # the per-dispatch trace of a 10k-launch run is large: keep the stats tables
 # the same bench command with one launch per step: its per-kernel average is what bench.py's roofline.single_launch reports
