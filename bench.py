@@ -122,8 +122,9 @@ def main():
     ap.add_argument("--n-substeps", type=int, default=4)
     ap.add_argument("--control-mode", default="faithful", choices=["faithful", "zoh"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"], help="f64 = the exactness build of the same kernels")
-    ap.add_argument("--flavour", default="baked", choices=["baked", "sym", "generic"],
-                    help="6-DoF kernel flavour: the reference's constants (literals), other BlueROV2-structured numbers "
+    ap.add_argument("--flavour", default="baked", choices=["baked", "ctrl", "sym", "generic"],
+                    help="6-DoF kernel flavour: the reference's constants (literals), the reference's vehicle with a retuned "
+                         "controller (vehicle literals + run-time PID numbers), other BlueROV2-structured numbers "
                          "(run-time constants, sparse forms), or arbitrary constants (dense 6 x 6 forms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=12345)
@@ -170,7 +171,9 @@ def main():
     vp = None
     if wl["model"] == "rov6" and args.flavour != "baked":
         from marinevehiclereinforcementlearning_amd import params as P_
-        vp = P_.rov6_params(m=12.0, Xuu=-19.0) if args.flavour == "sym" else P_.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3, m=12.0)
+        vp = {"ctrl": lambda: P_.rov6_params(K_P=[20., 25., 30., 8., 10., 1.2], K_D=[18., 20., 22., 5., 4., 0.7]),
+              "sym": lambda: P_.rov6_params(m=12.0, Xuu=-19.0),
+              "generic": lambda: P_.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3, m=12.0)}[args.flavour]()
     env = MarineVecEnv(wl["model"], n, seed=args.seed, n_substeps=args.n_substeps, control_mode=args.control_mode,
                        flow=flow, device=local_rank, env_offset=rank * n, infos="lean", precision=args.precision,
                        vehicle_params=vp)

@@ -177,6 +177,8 @@ int mvrl_model_dims(int32_t model, int32_t* act_dim, int32_t* obs_dim, int32_t* 
 int mvrl_aux_dim(int32_t model);
 /* Which kernel flavour the handle dispatches to, e.g. "rov6/baked/faithful+flow":
  *   baked   - runtime constants equal the reference's defaults bit-for-bit -> literals in the instruction stream
+ *   ctrl    - (6-DoF, fp32) the reference's vehicle with other PID gains / limits / action and observation scales: vehicle
+ *             constants as literals, the controller's 38 numbers read at run time
  *   sym     - BlueROV2-Heavy structure (sparse, sign-symmetric thruster layout), constants read at run time
  *   generic - arbitrary constants, dense matrices */
 const char* mvrl_variant(const mvrl_handle* h);

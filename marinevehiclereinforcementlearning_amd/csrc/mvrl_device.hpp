@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 #include <type_traits>
 
 #define MVRL_BLOCK 256
@@ -277,6 +278,12 @@ __device__ __forceinline__ float in_vgpr(float x) {
 #endif
 }
 
+// "ctrl" flavour: the reference's vehicle (literals) with a run-time controller - PID gains, wind-up and output limits,
+// action / observation scales are what users retune, the hull is not.  Rov6BakedVeh's ordinary members mirror the tail of
+// Rov6Dev from `kp` on, so the pointer is simply &params->kp in the constant address space (38 scalar-loaded words).
+typedef const __attribute__((address_space(4))) Rov6BakedVeh* CPV6;
+static_assert(sizeof(Rov6BakedVeh) == sizeof(Rov6Dev) - offsetof(Rov6Dev, kp), "Rov6BakedVeh must mirror the tail of Rov6Dev");
+
 // Baked flavour: `p->field` resolves to a static constexpr member, i.e. an instruction literal; nothing to launder.
 __device__ __forceinline__ const Rov6Baked* launder(const Rov6Baked* p) { return p; }
 __device__ __forceinline__ const Rov6Baked* launder_after(const Rov6Baked* p, float&) { return p; }
@@ -285,6 +292,8 @@ template <class PP, class T>
 __device__ __forceinline__ PP param_ptr(const T* pg) {
     if constexpr (std::is_same<PP, const Rov6Baked*>::value || std::is_same<PP, const Rov3Baked*>::value) {
         return nullptr;  // never dereferenced: every member is static
+    } else if constexpr (std::is_same<PP, CPV6>::value) {
+        return (PP)(uintptr_t)(&pg->kp[0]);
     } else {
         return (PP)(uintptr_t)pg;
     }

@@ -4,7 +4,7 @@
 
 namespace mvrl {
 
-hipError_t launch_rov6_step(const Rov6Dev* p_dev, const StepIO& io, const FlowDev& fl, bool baked, bool sym, bool zoh,
+hipError_t launch_rov6_step(const Rov6Dev* p_dev, const StepIO& io, const FlowDev& fl, bool baked, bool ctrl, bool sym, bool zoh,
                             bool flow, bool rk45, hipStream_t stream);
 hipError_t launch_rov6_derivs(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* t, const float* y, const float* sp,
                               float* eold, float* eint, float* told, const uint8_t* has_old, float* dy, float* aux,

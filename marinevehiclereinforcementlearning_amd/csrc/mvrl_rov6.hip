@@ -875,7 +875,7 @@ hipError_t launch_rov6_derivs(const Rov6Dev* p, bool baked, bool sym, int64_t n,
     return hipGetLastError();
 }
 
-hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool sym, bool zoh,
+hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool ctrl, bool sym, bool zoh,
                             bool flow, bool rk45, hipStream_t stream) {
     dim3 grid((unsigned)((io.lane_end - io.lane0 + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
 #define MVRL_L6(S, Z, F) hipLaunchKernelGGL((rov6_step_kernel<CP6, S, Z, F, 0>), grid, block, 0, stream, p, io, fl)
@@ -893,14 +893,17 @@ hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& f
     // trip count): a roll-out of K steps and K single-step launches execute the same binary, hence the same roundings
     // (fast-math contraction is decided per instance; two instances of the same source may differ in the last bit).
 #if !MVRL_F64 && !defined(MVRL_SEPARATE_SINGLE)
-    if (baked || sym) {
+    if (baked || ctrl || sym) {
 #else
-    if (io.k_steps > 1) {
+    if (io.k_steps > 1 && (baked || ctrl || sym)) {
 #endif
 #define MVRL_L6M(PPT, Z, F) hipLaunchKernelGGL((rov6_step_kernel<PPT, true, Z, F, 0, true>), grid, block, 0, stream, p, io, fl)
         if (baked) {
             if (zoh) { if (flow) MVRL_L6M(const Rov6Baked*, true, true); else MVRL_L6M(const Rov6Baked*, true, false); }
             else { if (flow) MVRL_L6M(const Rov6Baked*, false, true); else MVRL_L6M(const Rov6Baked*, false, false); }
+        } else if (ctrl) {   // the reference's vehicle as literals, the controller's numbers at run time
+            if (zoh) { if (flow) MVRL_L6M(CPV6, true, true); else MVRL_L6M(CPV6, true, false); }
+            else { if (flow) MVRL_L6M(CPV6, false, true); else MVRL_L6M(CPV6, false, false); }
         } else {
             if (zoh) { if (flow) MVRL_L6M(CP6, true, true); else MVRL_L6M(CP6, true, false); }
             else { if (flow) MVRL_L6M(CP6, false, true); else MVRL_L6M(CP6, false, false); }
@@ -911,7 +914,7 @@ hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& f
     if (baked) {
         if (zoh) { if (flow) MVRL_L6B(true, true); else MVRL_L6B(true, false); }
         else { if (flow) MVRL_L6B(false, true); else MVRL_L6B(false, false); }
-    } else if (sym) {
+    } else if (sym || ctrl) {
         if (zoh) { if (flow) MVRL_L6(true, true, true); else MVRL_L6(true, true, false); }
         else { if (flow) MVRL_L6(true, false, true); else MVRL_L6(true, false, false); }
     } else {

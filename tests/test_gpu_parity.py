@@ -162,6 +162,13 @@ def test_generic_kernel_with_modified_constants(oracle_mod):
     h2 = _lib.Handle(P.make_config("rov6", n, auto_reset=False, max_steps=10 ** 9, use_flow=False, rov6=p6s))
     assert "sym" in h2.variant
     _audited_run(oracle_mod, 6, h2, n, steps, init, actions, rov6=p6s)
+    # the reference's vehicle with a retuned controller -> "ctrl": vehicle constants as literals, PID numbers at run time
+    p6c = P.rov6_params(K_P=[20., 25., 30., 8., 10., 1.2], K_D=[18., 20., 22., 5., 4., 0.7], K_I=[1., 2., 3., 0.1, 0.2, 0.2],
+                        forceMomentMaxMagnitudes=[40., 50., 45., 1., 1.5, 2.], windup=[1.5, 2., 2., 1.2, 1.5, 1.5])
+    hc = _lib.Handle(P.make_config("rov6", n, auto_reset=False, max_steps=10 ** 9, use_flow=False, rov6=p6c))
+    assert "ctrl" in hc.variant
+    _audited_run(oracle_mod, 6, hc, n, steps, init, actions, rov6=p6c)
+    hc.close()
     # 3-DoF with non-default numbers -> generic
     p3 = P.rov3_params(m=12.0, CG=[0.01, 0.02, 0.02], Yr=-0.2)
     init3, act3 = random_rov_batch(3, n, steps, 6)

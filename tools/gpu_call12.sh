@@ -1,0 +1,8 @@
+#!/bin/bash
+OUT=gpurun_out
+mkdir -p $OUT
+timeout -k 10 1100 python -m pytest tests -m gpu -q > $OUT/r2_t12.log 2>&1
+rc=$?; echo "pytest rc=$rc"; tail -6 $OUT/r2_t12.log | cut -c1-300
+if [ $rc -ge 124 ]; then exit $rc; fi
+timeout -k 10 200 python __graft_entry__.py smoke > $OUT/r2_smoke12.log 2>&1; echo "smoke rc=$?"; tail -2 $OUT/r2_smoke12.log | cut -c1-400
+bash tools/bench_table.sh > $OUT/r2_table2.log 2>&1; rc=$?; echo "table rc=$rc"; cat $OUT/r2_table2.log; if [ $rc -ge 124 ]; then exit $rc; fi
