@@ -34,26 +34,34 @@ def test_replicated_lanes_stay_identical(model, n):
 
 
 def test_kernel_flavours_agree_at_full_size():
-    """baked (literal constants) vs sym (run-time constants): same arithmetic, so identical to fp32 rounding."""
+    """baked (literal constants) vs ctrl (literal vehicle, run-time controller) vs sym (run-time constants): the same numbers
+    up to one fp32 ulp in one constant, the same arithmetic - so identical to fp32 rounding."""
     n = 262144
     rng = np.random.default_rng(9)
     init = np.concatenate([(rng.random((n, 6)) - 0.5) * 10, rng.random((n, 3)) * 2 * np.pi], axis=1).astype(np.float32)
     acts = rng.uniform(-1, 1, size=(5, n, 6)).astype(np.float32)
-    eps = 1e-9  # perturbs one constant by less than fp32 resolution?  no: use a genuinely different-but-equal path
     hb = _lib.Handle(P.make_config("rov6", n, auto_reset=False, max_steps=10 ** 9, use_flow=False))
-    p6 = P.rov6_params()
-    p6.kp[0] = 25.0 * (1 + 1e-7)   # differs from the default after fp32 narrowing -> not "baked", still structured
-    hs = _lib.Handle(P.make_config("rov6", n, auto_reset=False, max_steps=10 ** 9, use_flow=False, rov6=p6))
-    assert "baked" in hb.variant and "sym" in hs.variant
-    hb.reset(init=init); hs.reset(init=init)
+    pc = P.rov6_params()
+    pc.kp[0] = 25.0 * (1 + 1e-7)     # one fp32 ulp: no longer the reference's controller -> not "baked", vehicle untouched
+    hc = _lib.Handle(P.make_config("rov6", n, auto_reset=False, max_steps=10 ** 9, use_flow=False, rov6=pc))
+    ps = P.rov6_params()
+    ps.dlin[0] = ps.dlin[0] * (1 + 1.5e-7)   # one ulp in a vehicle constant (linear surge damping) -> structured run-time constants
+    hs = _lib.Handle(P.make_config("rov6", n, auto_reset=False, max_steps=10 ** 9, use_flow=False, rov6=ps))
+    assert "baked" in hb.variant and "ctrl" in hc.variant and "sym" in hs.variant, (hb.variant, hc.variant, hs.variant)
+    for h in (hb, hc, hs):
+        h.reset(init=init)
     for s in range(5):
-        hb.step(acts[s]); hs.step(acts[s])
-    a, b = hb.get_state()[:12], hs.get_state()[:12]
-    d = np.abs(a - b)
-    d[3:6] = np.minimum(d[3:6], np.abs(d[3:6] - 2 * np.pi))
-    bad = (d / np.maximum(1, np.abs(a))).max(axis=0) > 1e-4
-    assert bad.mean() < 1e-3, bad.sum()
-    hb.close(); hs.close()
+        for h in (hb, hc, hs):
+            h.step(acts[s])
+    a = hb.get_state()[:12]
+    for h in (hc, hs):
+        b = h.get_state()[:12]
+        d = np.abs(a - b)
+        d[3:6] = np.minimum(d[3:6], np.abs(d[3:6] - 2 * np.pi))
+        bad = (d / np.maximum(1, np.abs(a))).max(axis=0) > 1e-4
+        assert bad.mean() < 1e-3, (h.variant, bad.sum())
+    for h in (hb, hc, hs):
+        h.close()
 
 
 def test_episode_accounting_at_full_size():
