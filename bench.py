@@ -396,7 +396,11 @@ def main():
                 if ent and tj.get("kernel_source_hash") == khash and n == wl["n"] and args.precision == "f32" \
                         and args.control_mode == "faithful" and args.n_substeps == 4 and not args.rollout:
                     traffic = ent.get("hbm_bytes_per_step")
-                    traffic_src = {"file": "profiles/r02_counters.json", "kernel_source_hash": khash, "commit": tj.get("commit")}
+                    traffic_src = {"file": "profiles/r02_counters.json", "kernel_source_hash": khash, "commit": tj.get("commit"),
+                                   # rocprofv3 --kernel-trace --stats of this command under either launch plan: a chains launch
+                                   # (half the batch, two in flight) lasts about one step; a single launch IS one step
+                                   "rocprof_kernel_avg_us": {"chains": ent.get("bench_command_kernel_avg_us"),
+                                                             "single": ent.get("chains1_kernel_avg_us")}}
                     if "valu" in ent:
                         v = dict(ent["valu"])
                         # achieved VALU issue rate of THIS run from the committed instruction count and the live time

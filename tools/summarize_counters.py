@@ -25,12 +25,18 @@ OUT = os.path.join(REPO, "gpurun_out")
 PROF = os.path.join(REPO, "profiles")
 
 
+def newest(pattern):
+    """gpurun merges the output of several sessions into gpurun_out/: one rocprofv3 run = one <pid> file set; take the latest"""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 def counters(tag, kernel_substr):
     acc, dur = {}, []
     for d in sorted(glob.glob(os.path.join(OUT, f"prof_{tag}_pmc*"))):
         if not os.path.isdir(d):
             continue
-        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for f in newest(os.path.join(d, "*", "*_counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 if kernel_substr in r["Kernel_Name"]:
                     acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
@@ -43,7 +49,7 @@ def main():
     tag, wl, kernel_substr, n_envs, alg_read, alg_bytes = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5]), float(sys.argv[6])
     from marinevehiclereinforcementlearning_amd import build
     os.makedirs(PROF, exist_ok=True)
-    ks = glob.glob(os.path.join(OUT, f"prof_{tag}_kt", "*", "*_kernel_stats.csv"))
+    ks = newest(os.path.join(OUT, f"prof_{tag}_kt", "*", "*_kernel_stats.csv"))
     avg_ns = calls = None
     if ks:
         rows = list(csv.reader(open(ks[0])))
@@ -56,7 +62,7 @@ def main():
                 calls, avg_ns = int(r[1]), float(r[3])
                 break
     avg1_ns = calls1 = None
-    ks1 = glob.glob(os.path.join(OUT, f"prof_{tag}_kt1", "*", "*_kernel_stats.csv"))
+    ks1 = newest(os.path.join(OUT, f"prof_{tag}_kt1", "*", "*_kernel_stats.csv"))
     if ks1:
         rows = list(csv.reader(open(ks1[0])))
         with open(os.path.join(PROF, f"{tag}_chains1_kernel_stats.csv"), "w", newline="") as f:
