@@ -421,6 +421,8 @@ hipError_t launch_rov3_derivs(const Rov3Dev* p, bool baked, int64_t n, const flo
     return hipGetLastError();
 }
 
+// (Capping the 75-89-VGPR 3-DoF kernels at four waves per SIMD with a dynamic-LDS allocation was measured: 94.0 vs 93.1 us
+// per step at 1 048 576 envs, 65.9 vs 63.7 us with ZOH - no gain, not adopted; gpurun_out/r2_ab14.log.)
 hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool zoh, bool flow,
                             bool rk45, hipStream_t stream) {
     dim3 grid((unsigned)((io.lane_end - io.lane0 + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
@@ -449,6 +451,7 @@ hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& f
 #undef MVRL_L3M
         return hipGetLastError();
     }
+#if MVRL_F64 || defined(MVRL_SEPARATE_SINGLE)   /* fp32: everything was dispatched above */
     if (baked) {
         if (zoh) { if (flow) MVRL_L3(const Rov3Baked*, true, true); else MVRL_L3(const Rov3Baked*, true, false); }
         else { if (flow) MVRL_L3(const Rov3Baked*, false, true); else MVRL_L3(const Rov3Baked*, false, false); }
@@ -456,6 +459,7 @@ hipError_t launch_rov3_step(const Rov3Dev* p, const StepIO& io, const FlowDev& f
         if (zoh) { if (flow) MVRL_L3(CP3, true, true); else MVRL_L3(CP3, true, false); }
         else { if (flow) MVRL_L3(CP3, false, true); else MVRL_L3(CP3, false, false); }
     }
+#endif
 #undef MVRL_L3
     return hipGetLastError();
 }

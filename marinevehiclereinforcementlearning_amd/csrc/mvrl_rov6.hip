@@ -911,13 +911,16 @@ hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& f
 #undef MVRL_L6M
         return hipGetLastError();
     }
+#if MVRL_F64 || defined(MVRL_SEPARATE_SINGLE)   /* fp32: these flavours were dispatched above - no second instance of them */
     if (baked) {
         if (zoh) { if (flow) MVRL_L6B(true, true); else MVRL_L6B(true, false); }
         else { if (flow) MVRL_L6B(false, true); else MVRL_L6B(false, false); }
     } else if (sym || ctrl) {
         if (zoh) { if (flow) MVRL_L6(true, true, true); else MVRL_L6(true, true, false); }
         else { if (flow) MVRL_L6(true, false, true); else MVRL_L6(true, false, false); }
-    } else {
+    } else
+#endif
+    {
         if (zoh) { if (flow) MVRL_L6(false, true, true); else MVRL_L6(false, true, false); }
         else { if (flow) MVRL_L6(false, false, true); else MVRL_L6(false, false, false); }
     }
