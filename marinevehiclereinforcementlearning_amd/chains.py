@@ -32,31 +32,21 @@ class ChainStepper:
         dev = torch.device("cuda", env.cfg.device)
         self.streams = streams or [torch.cuda.Stream(device=dev) for _ in range(self.n_chains)]
         self.stagger = bool(stagger) and self.n_chains > 1
-        self._armed = False
-        self._ev = [torch.cuda.Event() for _ in range(self.n_chains)]
 
     def fork(self):
-        """Every chain waits for what is queued on the current stream (actions written there, a reset, ...).  The first step
-        after a fork is staggered: chain c starts when chain 0 has finished the first c/n_chains of its lanes, so that the
-        chains' launches end at different times from then on (kernels that start together end together, and their tails
-        and launch gaps would coincide again)."""
+        """Every chain waits for what is queued on the current stream (actions written there, a reset, ...)."""
         cur = torch.cuda.current_stream()
         for s in self.streams:
             s.wait_stream(cur)
-        self._armed = self.stagger
-
-    def arm(self):
-        """Stagger the next step without a fork (the caller has synchronised the device itself): chains that start in the same
-        instant also end together - their launch gaps and tails coincide and nothing overlaps them until the chains have
-        drifted apart, which takes tens of steps."""
-        self._armed = self.stagger
 
     def phase_delay(self, step_us):
         """Start chain c about c / n_chains of a step late, WITHOUT a cross-stream dependency: a one-wave kernel that spins for
         that long is queued on the chain's stream ahead of its next launch (mvrl_delay_dev).  Chains that start in the same
         instant also end in the same instant, launch after launch, until they happen to drift apart (tens of steps); with
-        the offset the second chain's kernel covers the first chain's launch gap and tail from the first step on.  Call it
-        with every stream idle (e.g. after a device synchronise) and a rough step time in microseconds."""
+        the offset the second chain's kernel covers the first chain's launch gap and tail from the first step on.  (Making
+        chain c wait for an event inside chain 0's first step does the same but costs more than it gains: a cross-stream
+        wait takes the command processor 10-20 us.)  Call it with every stream idle (e.g. after a device synchronise) and a
+        rough step time in microseconds; long runs do not need it."""
         if not self.stagger or step_us <= 0:
             return
         for c in range(1, self.n_chains):
@@ -69,25 +59,9 @@ class ChainStepper:
         assert tuple(actions.shape) == (env.num_envs, env.action_space.shape[0])
         obs, rew, done = out if out is not None else env._ensure_tensors()
         ptrs = (actions.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
-        raw = [s.cuda_stream for s in self.streams]
         launch = env.handle.step_range_dev           # enqueues on the given raw stream: no torch stream switch needed
-        if self._armed:
-            self._armed = False
-            lo0, cnt0 = self.ranges[0]
-            C = self.n_chains
-            w0 = (cnt0 + 63) // 64
-            cuts = [lo0 + min(cnt0, 64 * ((w0 * j) // C)) for j in range(C)] + [lo0 + cnt0]
-            for j in range(C):
-                if cuts[j + 1] > cuts[j]:
-                    launch(cuts[j], cuts[j + 1] - cuts[j], *ptrs, raw[0])
-                if j < C - 1:
-                    self._ev[j].record(self.streams[0])
-            for c in range(1, C):
-                self.streams[c].wait_event(self._ev[c - 1])
-                launch(self.ranges[c][0], self.ranges[c][1], *ptrs, raw[c])
-            return obs, rew, done
-        for c, (lo, cnt) in enumerate(self.ranges):
-            launch(lo, cnt, *ptrs, raw[c])
+        for (lo, cnt), s in zip(self.ranges, self.streams):
+            launch(lo, cnt, *ptrs, s.cuda_stream)
         return obs, rew, done
 
     def join(self):
