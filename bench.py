@@ -440,6 +440,8 @@ def main():
                        "collective_in_value": "none: shards are independent, outputs stay in each rank's HBM"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_per": "env step of the whole batch, like `achieved` (one launch under the single plan, "
+                                        "C lane-range launches under chains); FETCH_SIZE x 2 + WRITE_SIZE from separate --pmc passes",
                          "kernel_us_per_step": per_step_s * 1e6, "kernel_launches_per_step": launches / max(1e-9, steps_per_region),
                          "algorithmic_bytes_per_env_step": wl["bytes"], "valu": valu, "kernel_source_hash": khash,
                          "single_launch": None if single is None else {
