@@ -272,6 +272,20 @@ int mvrl_derivs(mvrl_handle* h, int64_t n, const float* t, const float* y, const
 int mvrl_derivs_f64(mvrl_handle* h, int64_t n, const double* t, const double* y, const double* sp, double* eold, double* eint,
                     double* told, const uint8_t* has_old, double* dy, double* gcf, double* rpm);
 
+/* ---- unit-level operators of the 6-DoF vehicle for n independent tuples (host arrays; NULL inputs / outputs are skipped), each
+ * evaluated by the device functions the step kernel runs - the public methods example_trialTrajectories.py:100-134 and the
+ * demos call on the vehicle object:
+ *   axes[n,9]     rows iHat, jHat, kHat of updateMovingCoordSystem(angles)   6DoF.py:238-242  (globalToVehicle(v) = axes . v, :244-248)
+ *   rpm_out[n,8]  allocateThrust() for generalisedControlForces = gcf[n,6] at `angles`   6DoF.py:220-231
+ *   rhs[n,6]      forceModel(pos, angles, vel, rpm)[1]                        6DoF.py:253-404
+ *   thruster_h[n,6]  the thruster column H of forceModel(..., retComp=True) = A . thrusterModel(limit(rpm))   :233-236, :271-282
+ * with rpm = rpm_in[n,8] if given, else the allocation of gcf.  vel NULL = zero velocity.  (M itself is constant:
+ * mvrl_rov6_params.mass.) ---- */
+int mvrl_vehicle_ops(mvrl_handle* h, int64_t n, const float* angles, const float* gcf, const float* rpm_in, const float* vel,
+                     float* axes, float* rpm_out, float* rhs, float* thruster_h);
+int mvrl_vehicle_ops_f64(mvrl_handle* h, int64_t n, const double* angles, const double* gcf, const double* rpm_in, const double* vel,
+                         double* axes, double* rpm_out, double* rhs, double* thruster_h);
+
 /* Per-step side outputs the reference keeps in timeHistory (6DoF.py:578-587: F0..F5, u0..u7; 3DoF: F0..F2,u0..u3;
  * verySimpleAuv.py:389-403: Fx,Fy,N,u_current,v_current,rmsAc,r0..r4).  Enable BEFORE stepping;
  * aux row = [n_envs, aux_dim] f32 with aux_dim = 14 (ROV6) / 7 (ROV3) / 11 (AUV). */

@@ -28,7 +28,7 @@ SYMBOLS = [
     "mvrl_dev_upload", "mvrl_dev_download", "mvrl_synchronize",
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
-    "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64",
+    "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64", "mvrl_vehicle_ops", "mvrl_vehicle_ops_f64",
     "mvrl_auv_pd_episodes_dev", "mvrl_rollout_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
@@ -104,6 +104,8 @@ def load(path=None):
     lib.mvrl_get_nfev.argtypes = [vp, vp]
     lib.mvrl_derivs.argtypes = [vp, i64] + [vp] * 10
     lib.mvrl_derivs_f64.argtypes = [vp, i64] + [vp] * 10
+    lib.mvrl_vehicle_ops.argtypes = [vp, i64] + [vp] * 8
+    lib.mvrl_vehicle_ops_f64.argtypes = [vp, i64] + [vp] * 8
     lib.mvrl_rollout_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.mvrl_auv_pd_episodes_dev.argtypes = [vp, vp, vp, C.c_double, i32, vp, vp, vp]
     lib.mvrl_replay_add_sym_dev.argtypes = [i32] + [vp] * 5 + [i64] + [vp] * 6 + [i64, i64, i32, i32, vp]
@@ -270,6 +272,32 @@ class Handle:
         check(self._fn("mvrl_derivs")(self.h, n, t.ctypes.data, y.ctypes.data, sp.ctypes.data, eo.ctypes.data, ei.ctypes.data,
                                       to.ctypes.data, ho.ctypes.data, dy.ctypes.data, gcf.ctypes.data, rpm.ctypes.data), self.h)
         return dict(dy=dy, eold=eo, eint=ei, told=to, gcf=gcf, rpm=rpm)
+
+    def vehicle_ops(self, angles, gcf=None, rpm=None, vel=None, want=("axes", "rpm", "rhs", "thruster_h")):
+        """Body axes / allocateThrust / forceModel of the 6-DoF vehicle for n tuples (mvrl_vehicle_ops).  Returns a dict with
+        the requested outputs that the inputs allow: axes [n,3,3] always; rpm [n,8] needs gcf; rhs / thruster_h [n,6] use
+        rpm if given, else the allocation of gcf."""
+        ang = np.ascontiguousarray(np.atleast_2d(angles), self.dtype)
+        n = ang.shape[0]
+
+        def arr(x, w):
+            return None if x is None else _real(np.atleast_2d(x), self.dtype, (n, w))
+        g, r, v = arr(gcf, 6), arr(rpm, 8), arr(vel, 6)
+        out = {}
+        if "axes" in want:
+            out["axes"] = np.zeros((n, 3, 3), self.dtype)
+        if "rpm" in want and g is not None:
+            out["rpm"] = np.zeros((n, 8), self.dtype)
+        if g is not None or r is not None or v is not None:
+            for k in ("rhs", "thruster_h"):
+                if k in want:
+                    out[k] = np.zeros((n, 6), self.dtype)
+
+        def p(a):
+            return None if a is None else a.ctypes.data
+        check(self._fn("mvrl_vehicle_ops")(self.h, n, ang.ctypes.data, p(g), p(r), p(v), p(out.get("axes")), p(out.get("rpm")),
+                                           p(out.get("rhs")), p(out.get("thruster_h"))), self.h)
+        return out
 
     def enable_aux(self, on=True):
         check(self.lib.mvrl_enable_aux(self.h, 1 if on else 0), self.h)

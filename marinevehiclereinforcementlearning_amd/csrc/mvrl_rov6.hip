@@ -132,9 +132,11 @@ __device__ __forceinline__ void allocate6(PP p, const Axes& a, const float* u, f
 }
 
 // forceModel + solve + kinematics (6DoF.py:253-442) for given limited thruster forces.
+// rhs_out / h_out (may be null; constant-folded away in the step kernels): forceModel's second return value RHS and the
+// thruster column H of its retComp breakdown - the unit-level entry point (rov6_unit_kernel)
 template <bool SYM, bool FLOW, class PP>
 __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, const Axes& ax,
-                                          const float* F, float2 cur, float* dy) {
+                                          const float* F, float2 cur, float* dy, float* rhs_out = nullptr, float* h_out = nullptr) {
     p = launder(p);
     const float u = y[6], v = y[7], w = y[8], pp = y[9], q = y[10], r = y[11];
     float nr0 = u, nr1 = v, nr2 = w;  // relative velocity (only the translational part sees the current)
@@ -189,6 +191,7 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
         R[3] = H3 - c3 - ca3 - d3 - g3;
         R[4] = H4 - c4 - ca4 - d4 - g4;
         R[5] = H5 - c5 - ca5 - d5;
+        if (h_out) { h_out[0] = H0; h_out[1] = H1; h_out[2] = H2; h_out[3] = H3; h_out[4] = H4; h_out[5] = H5; }
         // M^-1 with the (u,q)/(v,p) couplings only (6DoF.py:286-299, :428)
         dy[6] = p->minv[0] * R[0] + p->minv[4] * R[4];
         dy[7] = p->minv[7] * R[1] + p->minv[9] * R[3];
@@ -234,6 +237,7 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
                 c2 = fmaf(Ca[6 * i + j] + dij, vr[j], c2);
             }
             R[i] = -c1 - c2 - G[i] + h;
+            if (h_out) h_out[i] = h;
         }
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -243,6 +247,10 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
             for (int j = 0; j < 6; j++) a = fmaf(p->minv[6 * i + j], R[j], a);
             dy[6 + i] = a;
         }
+    }
+    if (rhs_out) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) rhs_out[i] = R[i];
     }
     // eta_dot = J(eta) nu (resources.py:98-143) - with the reference's J1[0,2] = s(psi)s(phi) + c(psi)s(theta)s(phi)
     // and the cos(theta) guard (:116-120)
@@ -862,6 +870,66 @@ __global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov6_derivs_kernel(const Rov6
 #pragma unroll
     for (int k = 0; k < 6; k++) { eold[i * 6 + k] = pid.eold[k]; eint[i * 6 + k] = pid.eint[k]; }
     told[i] = to;
+}
+
+// Unit-level operators of the vehicle for n independent tuples (mvrl_vehicle_ops), each through the device functions the
+// step kernel runs: body axes (updateMovingCoordSystem, 6DoF.py:238-242), allocateThrust (:220-231) and forceModel
+// (:253-404: RHS and the thruster column H) with the thrusters' saturation / dead-band in force space.
+template <class PP, bool SYM>
+__global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov6_unit_kernel(const Rov6Dev* __restrict__ pg, int64_t n, const float* angles,
+                                                                    const float* gcf, const float* rpm_in, const float* vel,
+                                                                    float* axes_out, float* rpm_out, float* rhs_out, float* h_out) {
+    const PP p = param_ptr<PP>(pg);
+    const int64_t i = (int64_t)blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float y[12] = {0.f, 0.f, 0.f, angles[i * 3], angles[i * 3 + 1], angles[i * 3 + 2], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (vel) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) y[6 + k] = vel[i * 6 + k];
+    }
+    const Trig6 t = trig6(y);
+    const Axes ax = body_axes(t);
+    if (axes_out) {
+        float* a = axes_out + i * 9;
+        a[0] = ax.i0; a[1] = ax.i1; a[2] = ax.i2; a[3] = ax.j0; a[4] = ax.j1; a[5] = ax.j2; a[6] = ax.k0; a[7] = ax.k1; a[8] = ax.k2;
+    }
+    float F[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cv[8];
+    if (gcf) {
+        float u[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) u[k] = gcf[i * 6 + k];
+        allocate6<SYM>(p, ax, u, F, cv);
+        if (rpm_out) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) rpm_out[i * 8 + k] = force_to_rpm(p, cv[k]);
+        }
+    }
+    if (rpm_in) {   // thrusterModel(limit(rpm)) (6DoF.py:233-236, :271-275) in force space
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const float r = rpm_in[i * 8 + k] * (1.0f / 60.f);
+            F[k] = limit_force(p, p->thrust_k * r * r * fsign(r));
+        }
+    }
+    if (rhs_out || h_out) {
+        float dy[12], R[6], H[6];
+        dynamics6<SYM, false>(p, y, t, ax, F, make_float2(0.f, 0.f), dy, R, H);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            if (rhs_out) rhs_out[i * 6 + k] = R[k];
+            if (h_out) h_out[i * 6 + k] = H[k];
+        }
+    }
+}
+
+hipError_t launch_rov6_unit(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* angles, const float* gcf,
+                            const float* rpm_in, const float* vel, float* axes, float* rpm_out, float* rhs, float* h_out,
+                            hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
+    if (baked) hipLaunchKernelGGL((rov6_unit_kernel<const Rov6Baked*, true>), grid, block, 0, stream, p, n, angles, gcf, rpm_in, vel, axes, rpm_out, rhs, h_out);
+    else if (sym) hipLaunchKernelGGL((rov6_unit_kernel<CP6, true>), grid, block, 0, stream, p, n, angles, gcf, rpm_in, vel, axes, rpm_out, rhs, h_out);
+    else hipLaunchKernelGGL((rov6_unit_kernel<CP6, false>), grid, block, 0, stream, p, n, angles, gcf, rpm_in, vel, axes, rpm_out, rhs, h_out);
+    return hipGetLastError();
 }
 
 // ---- host-side launchers ---------------------------------------------------------------------------

@@ -2,7 +2,10 @@
 their own `solve_ivp`, as dynamicsModel_BlueROV2_Heavy_6DoF.py:686-745 and example_trialTrajectories.py:66-146 do):
 
     BlueROV2Heavy6DoF_PID_controller(setPoint)   6DoF.py:27-73   (memory: eOld / eInt / tOld, reset())
-    BlueROV2Heavy6DoF(controller)                6DoF.py:75-442  (derivs(t, state); generalisedControlForces, rpm)
+    BlueROV2Heavy6DoF(controller)                6DoF.py:75-442  (derivs(t, state); generalisedControlForces, rpm;
+                                                 updateMovingCoordSystem / globalToVehicle / vehicleToGlobal,
+                                                 allocateThrust, forceModel -> (M, RHS): the public methods
+                                                 example_trialTrajectories.py:100-134 calls)
     BlueROV2Heavy3DoF(setPoint)                  3DoF.py:25-296  (controller inlined in the vehicle, as in the reference)
 
 `derivs` is evaluated by the HIP kernels through `mvrl_derivs` (one lane per call here; `Handle.derivs` takes batches).
@@ -62,9 +65,40 @@ class BlueROV2Heavy6DoF(_Vehicle):
     def __init__(self, controller, precision="f64", **overrides):
         self.controller = controller
         self._open(precision, **overrides)
+        self._angles = np.zeros(3)
+        self.iHat, self.jHat, self.kHat = np.eye(3)
+        self.controlVector = np.zeros(8)
 
     def _memory(self):
         return self.controller
+
+    # ---- the vehicle's other public methods, evaluated on the GPU through mvrl_vehicle_ops -----------------------------------
+    def updateMovingCoordSystem(self, rotation_angles):
+        """6DoF.py:238-242: sets iHat, jHat, kHat for the XYZ-intrinsic attitude."""
+        self._angles = np.asarray(rotation_angles, np.float64)
+        ax = self._h.vehicle_ops(self._angles[None], want=("axes",))["axes"][0].astype(np.float64)
+        self.iHat, self.jHat, self.kHat = ax[0], ax[1], ax[2]
+
+    def globalToVehicle(self, vecGlobal):
+        """6DoF.py:244-248"""
+        return np.array([np.dot(vecGlobal, self.iHat), np.dot(vecGlobal, self.jHat), np.dot(vecGlobal, self.kHat)])
+
+    def vehicleToGlobal(self, vecVehicle):
+        """6DoF.py:250-251"""
+        return vecVehicle[0] * self.iHat + vecVehicle[1] * self.jHat + vecVehicle[2] * self.kHat
+
+    def allocateThrust(self):
+        """6DoF.py:220-231: rpm demands for self.generalisedControlForces at the attitude of the last updateMovingCoordSystem."""
+        r = self._h.vehicle_ops(self._angles[None], gcf=np.asarray(self.generalisedControlForces, np.float64)[None], want=("rpm",))
+        self.controlVector = r["rpm"][0].astype(np.float64)
+        return self.controlVector
+
+    def forceModel(self, pos, angles, vel, controlVector):
+        """6DoF.py:253-404: (M, RHS) for the given attitude, body velocities and thruster rpm."""
+        r = self._h.vehicle_ops(np.asarray(angles, np.float64)[None], rpm=np.asarray(controlVector, np.float64)[None],
+                                vel=np.asarray(vel, np.float64)[None], want=("rhs",))
+        M = np.array(self._h.cfg.rov6.mass, dtype=np.float64).reshape(6, 6)
+        return M, r["rhs"][0].astype(np.float64)
 
 
 class BlueROV2Heavy3DoF(_Vehicle):

@@ -254,3 +254,39 @@ def test_benched_auv_instance_at_full_size_vs_oracle(oracle_mod):
         assert np.max((np.abs(rew[li].cpu().numpy() - r_ref) / np.maximum(1.0, np.abs(r_ref)))[a]) < 3e-5, k
     assert alive.mean() > 0.99
     env.close()
+
+
+def test_chains_soak_bit_identical_at_full_size():
+    """Race check at BASELINE's full size: 1 048 576 6-DoF envs with turbulence stepped 600 times - three generations of
+    random auto-resets - once as whole-batch launches on one stream and once as two independent chains of lane ranges that
+    run ahead of each other on two streams (no host synchronisation in between).  Final state planes, episode counters,
+    terminal observations and the last outputs must agree bit for bit."""
+    import torch
+    from marinevehiclereinforcementlearning_amd.chains import ChainStepper
+    from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
+    n, steps = 1048576, 600
+    flow = _bench_flow()
+    kw = dict(seed=77, maxSteps=200, flow=flow, infos="lean")
+    a, b = MarineVecEnv("rov6", n, **kw), MarineVecEnv("rov6", n, **kw)
+    ring = torch.empty((8, n, 6), dtype=torch.float32, device="cuda")
+    for r in range(8):
+        a.handle.fill_uniform_dev(ring[r].data_ptr(), n * 6, 5, r, -1.0, 1.0, torch.cuda.current_stream().cuda_stream)
+    a.reset_tensors(); b.reset_tensors()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        oa, ra, da = a.step_tensors(ring[k % 8])
+    st = ChainStepper(b, n_chains=2)
+    st.fork()
+    st.phase_delay(60.0)
+    for k in range(steps):
+        ob, rb, db = st.step(ring[k % 8])
+    st.join()
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa, sb)
+    assert np.array_equal(a.handle.terminal_obs(), b.handle.terminal_obs())
+    ep = a.handle.episode_counter()
+    assert int(ep.min()) == 4 and int(ep.max()) == 4          # the initial reset + three auto-resets, every env
+    assert torch.isfinite(oa).all().item()
+    a.close(); b.close()
