@@ -42,7 +42,7 @@ def load(path=None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or os.environ.get("MVRL_LIB", LIB_PATH)
+    path = path or os.environ.get("MVRL_LIB") or LIB_PATH
     # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  If libmvrl.so pulled in the
     # system copy first, a later `import torch` would bring up a second runtime that sees no GPU.  Importing torch
     # first (when it is installed) makes both share torch's copy (same soname).

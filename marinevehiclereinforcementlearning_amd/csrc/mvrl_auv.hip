@@ -195,7 +195,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     if (i >= (uint32_t)io.lane_end) return;
     const uint32_t n32 = (uint32_t)io.n;
     char* const stb = reinterpret_cast<char*>(io.state);
-#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) * (uint32_t)sizeof(float))))
+#define ST(k) (*reinterpret_cast<float*>(stb + ((uint32_t)(k) * (n32 * (uint32_t)sizeof(float)) + i * (uint32_t)sizeof(float))))
     const bool cyl = p.n_wp > 0;
     AuvLane s;
     MVRL_AUV_LOAD_LANE(s);
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_pd_episode_kernel(const AuvDev
     if (i >= (uint32_t)n) return;
     const uint32_t n32 = (uint32_t)n;
     char* const stb = reinterpret_cast<char*>(state);
-#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) * (uint32_t)sizeof(float))))
+#define ST(k) (*reinterpret_cast<float*>(stb + ((uint32_t)(k) * (n32 * (uint32_t)sizeof(float)) + i * (uint32_t)sizeof(float))))
     AuvLane s;
     MVRL_AUV_LOAD_LANE(s);
     const float P[3] = {p0, p1, p2}, D[3] = {d0, d1, d2};
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_rollout_kernel(const AuvDev p,
     if (i >= (uint32_t)io.lane_end) return;
     const uint32_t n32 = (uint32_t)io.n;
     char* const stb = reinterpret_cast<char*>(io.state);
-#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + i) * (uint32_t)sizeof(float))))
+#define ST(k) (*reinterpret_cast<float*>(stb + ((uint32_t)(k) * (n32 * (uint32_t)sizeof(float)) + i * (uint32_t)sizeof(float))))
     const bool cyl = p.n_wp > 0;
     AuvLane s;
     MVRL_AUV_LOAD_LANE(s);

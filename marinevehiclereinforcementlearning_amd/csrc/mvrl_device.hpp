@@ -206,6 +206,10 @@ struct Rov6Dev {
     //   sym_ainv = |Ainv[0,0]| |Ainv[0,1]| |Ainv[0,5]| |Ainv[4,0]| |Ainv[4,1]| |Ainv[4,2]| |Ainv[4,3]| |Ainv[4,4]|
     float sym_a[8];
     float sym_ainv[8];
+    // Coriolis constants of the structured (SYM) right-hand side, grouped by velocity product (dynamics6):
+    //   m z_g,  m - added[2],  m - added[1],  m - added[0],
+    //   Izz - Iyy + added[4] - added[5],  Ixx - Izz + added[5] - added[3],  Iyy - Ixx + added[3] - added[4],  0
+    float sym_c[8];
     float thrust_k, inv_thrust_k, rpm_max, rpm_dead, f_max, f_dead;
     float kp[6], ki[6], kd[6], windup[6], umax[6];
     float act_scale[6];

@@ -182,7 +182,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     if (i_in >= (uint32_t)io.lane_end) return;
     const uint32_t n32 = (uint32_t)io.n;  // see mvrl_rov6.hip: 32-bit byte offsets -> saddr addressing
     char* const stb = reinterpret_cast<char*>(io.state);
-#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) * (uint32_t)sizeof(float))))
+#define ST(k) (*reinterpret_cast<float*>(stb + ((uint32_t)(k) * (n32 * (uint32_t)sizeof(float)) + LANE * (uint32_t)sizeof(float))))
 #define LANE i_k
     const int k_steps = MULTI ? io.k_steps : 1;
     // state: loaded before the first step of a launch, stored after the last, in registers in between (mvrl_rov6.hip)

@@ -50,9 +50,12 @@ __device__ __forceinline__ Axes body_axes(const Trig6& t) {
 // noise times 1e9.  -dpose IS that difference (the set-point is constant inside a step), accurate to 1e-7
 // relative; it is used whenever it agrees with the rounded difference (it does not across a yaw-error branch
 // change, where the rounded difference is the right one).
+//
+// half_dtp = (t - tOld) / 2 (trapezoidal integral); kd_inv[i] = K_D[i] / max(1e-9, t - tOld), formed once per env step by the
+// caller (null when !HAS_DT: the floor, K_D[i] * 1e9, a compile-time constant in the baked flavour).
 template <bool HAS_DT, bool USE_INC, class PP>
-__device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6& s, float dtp,
-                                     float inv_den, const float* dpose, bool inc_valid, float* u) {
+__device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6& s, float half_dtp,
+                                     const float* kd_inv, const float* dpose, bool inc_valid, float* u) {
     p = launder(p);  // phase-local scalar loads of the constants (see mvrl_device.hpp)
     float e[6];
     e[0] = sp[0] - y[0]; e[1] = sp[1] - y[1]; e[2] = sp[2] - y[2];
@@ -69,10 +72,10 @@ __device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6
             const bool use = (i < 5) ? inc_valid : (inc_valid && fabsf(de - di) <= 1e-5f);
             de = use ? di : de;
         }
-        float dedt = de * inv_den;
-        if (HAS_DT) s.eint[i] = fmaf(0.5f * (s.eold[i] + e[i]), dtp, s.eint[i]);
+        if (HAS_DT) s.eint[i] = fmaf(s.eold[i] + e[i], half_dtp, s.eint[i]);
         s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
-        float v = fmaf(p->ki[i], s.eint[i], fmaf(p->kd[i], dedt, p->kp[i] * e[i]));
+        const float kdi = HAS_DT ? kd_inv[i] : p->kd[i] * 1e9f;
+        float v = fmaf(p->ki[i], s.eint[i], fmaf(kdi, de, p->kp[i] * e[i]));
         u[i] = clampf(v, -p->umax[i], p->umax[i]);
         s.eold[i] = e[i];
     }
@@ -156,41 +159,37 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
         const float H3 = fmaf(p->sym_a[4], vB, -p->sym_a[3] * hB);
         const float H4 = fmaf(p->sym_a[6], vC, p->sym_a[5] * hA);
         const float H5 = p->sym_a[7] * hC;
-        // rigid-body Coriolis with x_g = y_g = 0, diagonal inertia (6DoF.py:303-332)
-        const float m = p->m, zg = p->cg[2], Ixx = p->I[0], Iyy = p->I[4], Izz = p->I[8];
-        float mzr = m * zg * r, mw = m * w, mv = m * v, mu = m * u;
-        float a2 = m * (zg * pp - v), b2 = m * (zg * q + u);
-        float c0 = mzr * pp + mw * q - mv * r;
-        float c1 = -mw * pp + mzr * q + mu * r;
-        float c2 = -a2 * pp - b2 * q;
-        float c3 = -mzr * u + mw * v + a2 * w + (Izz - Iyy) * q * r;
-        float c4 = -mw * u - mzr * v + b2 * w + (Ixx - Izz) * pp * r;
-        float c5 = mv * u - mu * v + (Iyy - Ixx) * pp * q;
-        // added-mass Coriolis built from nu, applied to nu_r (6DoF.py:334-341, :396)
-        float Xu = p->added[0] * u, Yv = p->added[1] * v, Zw = p->added[2] * w;
-        float Kp = p->added[3] * pp, Mq = p->added[4] * q, Nr = p->added[5] * r;
-        float ca0 = -Zw * q + Yv * r;
-        float ca1 = Zw * pp - Xu * r;
-        float ca2 = -Yv * pp + Xu * q;
-        float ca3 = -Zw * nr1 + Yv * nr2 - Nr * q + Mq * r;
-        float ca4 = Zw * nr0 - Xu * nr2 + Nr * pp - Kp * r;
-        float ca5 = -Yv * nr0 + Xu * nr1 - Mq * pp + Kp * q;
+        // Rigid-body Coriolis (x_g = y_g = 0, diagonal inertia, 6DoF.py:303-332) and added-mass Coriolis (built from nu, applied
+        // to nu_r, :334-341, :396) share their velocity products; with S = Crb nu + Ca nu_r written out, the m v w / m u w / m u v
+        // terms of the moment rows cancel and the rest groups by product (sym_c, mvrl_device.hpp):
+        //   S0 = mzg r p + (m - A2) w q - (m - A1) v r        S3 = mzg (p w - r u) - A2 w nr1 + A1 v nr2 + c4 q r
+        //   S1 = (A2 - m) w p + mzg r q + (m - A0) u r        S4 = mzg (q w - r v) + A2 w nr0 - A0 u nr2 + c5 p r
+        //   S2 = -mzg (p^2 + q^2) + (m - A1) v p - (m - A0) u q   S5 = -A1 v nr0 + A0 u nr1 + c6 p q
+        // (A = added[], c4..c6 = inertia and added-inertia differences: zero for the default vehicle).  Each row of
+        // RHS = H - S - D nu_r - G (6DoF.py:396) is accumulated term by term onto the thruster entry.
+        const float mzg = p->sym_c[0], kw = p->sym_c[1], kv = p->sym_c[2], ku = p->sym_c[3];
+        const float A0u = p->added[0] * u, A1v = p->added[1] * v, A2w = p->added[2] * w;
+        const float rp = r * pp, wq = w * q, vr = v * r, wp = w * pp, rq = r * q, ur = u * r, vp = v * pp, uq = u * q, pq = pp * q;
+        R[0] = fmaf(kv, vr, fmaf(-kw, wq, fmaf(-mzg, rp, H0)));
+        R[1] = fmaf(-ku, ur, fmaf(-mzg, rq, fmaf(kw, wp, H1)));
+        R[2] = fmaf(ku, uq, fmaf(-kv, vp, fmaf(mzg, fmaf(pp, pp, q * q), H2)));
+        R[3] = fmaf(-p->sym_c[4], rq, fmaf(-A1v, nr2, fmaf(A2w, nr1, fmaf(mzg, ur - wp, H3))));
+        R[4] = fmaf(-p->sym_c[5], rp, fmaf(A0u, nr2, fmaf(-A2w, nr0, fmaf(mzg, vr - wq, H4))));
+        R[5] = fmaf(-p->sym_c[6], pq, fmaf(-A0u, nr1, fmaf(A1v, nr0, H5)));
         // damping: diagonal + the single off-diagonal D[4,2] = -Mww |w| (6DoF.py:345-370)
-        float d0 = fmaf(p->dquad[0], fabsf(u), p->dlin[0]) * nr0;
-        float d1 = fmaf(p->dquad[7], fabsf(v), p->dlin[7]) * nr1;
-        float d2 = fmaf(p->dquad[14], fabsf(w), p->dlin[14]) * nr2;
-        float d3 = fmaf(p->dquad[21], fabsf(pp), p->dlin[21]) * pp;
-        float d4 = fmaf(p->dquad[28], fabsf(q), p->dlin[28]) * q + fmaf(p->dquad[26], fabsf(w), p->dlin[26]) * nr2;
-        float d5 = fmaf(p->dquad[35], fabsf(r), p->dlin[35]) * r;
-        // hydrostatics (6DoF.py:374-388) with x_g = y_g = x_b = y_b = 0
-        float g0 = p->wb * t.sth, g1 = -p->wb * t.cth * t.sph, g2 = -p->wb * t.cth * t.cph;
-        float g3 = p->gw[2] * t.cth * t.sph, g4 = p->gw[2] * t.sth;
-        R[0] = H0 - c0 - ca0 - d0 - g0;
-        R[1] = H1 - c1 - ca1 - d1 - g1;
-        R[2] = H2 - c2 - ca2 - d2 - g2;
-        R[3] = H3 - c3 - ca3 - d3 - g3;
-        R[4] = H4 - c4 - ca4 - d4 - g4;
-        R[5] = H5 - c5 - ca5 - d5;
+        R[0] = fmaf(-fmaf(p->dquad[0], fabsf(u), p->dlin[0]), nr0, R[0]);
+        R[1] = fmaf(-fmaf(p->dquad[7], fabsf(v), p->dlin[7]), nr1, R[1]);
+        R[2] = fmaf(-fmaf(p->dquad[14], fabsf(w), p->dlin[14]), nr2, R[2]);
+        R[3] = fmaf(-fmaf(p->dquad[21], fabsf(pp), p->dlin[21]), pp, R[3]);
+        R[4] = fmaf(-fmaf(p->dquad[28], fabsf(q), p->dlin[28]), q, fmaf(-fmaf(p->dquad[26], fabsf(w), p->dlin[26]), nr2, R[4]));
+        R[5] = fmaf(-fmaf(p->dquad[35], fabsf(r), p->dlin[35]), r, R[5]);
+        // hydrostatics (6DoF.py:374-388) with x_g = y_g = x_b = y_b = 0: G = [wb s(th), -wb c(th)s(ph), -wb c(th)c(ph),
+        // gw_z c(th)s(ph), gw_z s(th), 0], and c(th)s(ph) = -kHat[1], c(th)c(ph) = kHat[2]
+        R[0] = fmaf(-p->wb, t.sth, R[0]);
+        R[1] = fmaf(-p->wb, ax.k1, R[1]);
+        R[2] = fmaf(p->wb, ax.k2, R[2]);
+        R[3] = fmaf(p->gw[2], ax.k1, R[3]);
+        R[4] = fmaf(-p->gw[2], t.sth, R[4]);
         if (h_out) { h_out[0] = H0; h_out[1] = H1; h_out[2] = H2; h_out[3] = H3; h_out[4] = H4; h_out[5] = H5; }
         // M^-1 with the (u,q)/(v,p) couplings only (6DoF.py:286-299, :428)
         dy[6] = p->minv[0] * R[0] + p->minv[4] * R[4];
@@ -255,7 +254,8 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
     // eta_dot = J(eta) nu (resources.py:98-143) - with the reference's J1[0,2] = s(psi)s(phi) + c(psi)s(theta)s(phi)
     // and the cos(theta) guard (:116-120)
     float cd = t.cth;
-    cd = (fabsf(cd) < 1e-12f) ? 1e-6f : ((fabsf(cd) < 1e-6f) ? 1e-6f * fsign(cd) : cd);
+    // |cd| < 1e-12 -> 1e-6; |cd| < 1e-6 -> 1e-6 sign(cd); else cd - as two clamps selected by the side cd is on
+    cd = (cd > -1e-12f) ? fmaxf(cd, 1e-6f) : fminf(cd, -1e-6f);
     float icd = 1.0f / cd;
     // J1 rows from the shared products: [0,1] = pB - pA, [0,2] = pC + pB (the reference's typo), [1,1] = pE + pF,
     // [1,2] = pH - pG, [2,1] = c(theta)s(phi) = -k1, [2,2] = c(theta)c(phi) = k2; column 0 = iHat(0), -jHat(0), -s(theta)
@@ -324,11 +324,12 @@ __device__ __forceinline__ void write_aux6(PP p, const float* u, const float* cv
 }
 
 template <bool SYM, bool FLOW, bool HAS_DT, bool USE_INC, class PP>
-__device__ __forceinline__ void derivs6(PP p, const float* y, const Trig6& t, const float* sp, Pid6& pid, float dtp, float inv_den,
-                                        const float* dpose, bool inc_valid, float2 cur, float* dy, float* aux_row) {
+__device__ __forceinline__ void derivs6(PP p, const float* y, const Trig6& t, const float* sp, Pid6& pid, float half_dtp,
+                                        const float* kd_inv, const float* dpose, bool inc_valid, float2 cur, float* dy,
+                                        float* aux_row) {
     Axes ax = body_axes(t);
     float u[6], F[8], cv[8];
-    pid6<HAS_DT, USE_INC>(p, y, sp, pid, dtp, inv_den, dpose, inc_valid, u);
+    pid6<HAS_DT, USE_INC>(p, y, sp, pid, half_dtp, kd_inv, dpose, inc_valid, u);
     allocate6<SYM>(p, ax, u, F, cv);
     if (aux_row) write_aux6(p, u, cv, aux_row);  // wave-uniform: last RHS call of the step, aux enabled
     dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, dy);
@@ -503,12 +504,14 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     uint32_t i_k = i_in;
     if (MULTI) asm volatile("" : "+v"(i_k));  // plane addresses are recomputed per step instead of living across the loop
     STAMP(0);
-    // plane k of env i = state[k * n + i] with a 32-bit element index: the access lowers to the
+    // plane k of env i = state[k * n + i] with a 32-bit BYTE offset k * (4 n) + 4 i: the access lowers to the
     // `global_load_dword v, v_off, s[base:base+1]` form (uniform 64-bit base in SGPRs + one 32-bit VGPR offset)
-    // instead of a 64-bit VGPR address pair per plane.  The host guarantees words * n < 2^30.
+    // instead of a 64-bit VGPR address pair per plane, and the plane term is scalar arithmetic: one v_add_u32 per plane.
+    // The host guarantees words * n < 2^30.
     const uint32_t n32 = (uint32_t)io.n;
     char* const stb = reinterpret_cast<char*>(io.state);
-#define ST(k) (*reinterpret_cast<float*>(stb + (((uint32_t)(k) * n32 + LANE) * (uint32_t)sizeof(float))))
+    const uint32_t plane_bytes = n32 * (uint32_t)sizeof(float);   // byte offset = k * plane_bytes (scalar) + 4 * lane: one VALU add per plane
+#define ST(k) (*reinterpret_cast<float*>(stb + ((uint32_t)(k) * plane_bytes + LANE * (uint32_t)sizeof(float))))
 #define LANE i_k
 
     // Issue order matters: vector loads return in order, and the turbulence gathers (a second, dependent HBM round
@@ -548,7 +551,16 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
 
     const float h_s = io.dt / (float)io.n_sub;
     const float h = in_vgpr(h_s), hh = in_vgpr(0.5f * h_s), h6 = in_vgpr(h_s / 6.f);
-    const float inv_hh = in_vgpr(1.0f / (0.5f * h_s));
+    // PID constants of the calls with t - tOld > 0 (FAITHFUL: stages 2 and 4, half a sub-step after the previous call; ZOH:
+    // one call per sub-step): half the interval and K_D over it
+    const float dt_pid = ZOH ? h_s : 0.5f * h_s;
+    const float half_dtp = in_vgpr(0.5f * dt_pid);
+    float kd_inv[6];
+    {
+        const float inv_dt_pid = in_vgpr(1.0f / dt_pid);
+#pragma unroll
+        for (int q = 0; q < 6; q++) kd_inv[q] = p->kd[q] * inv_dt_pid;
+    }
     float2 cur = make_float2(0.f, 0.f);
     if (FLOW) cur = flow_combine(tap);
     float* const aux_row = io.aux ? io.aux + (size_t)i_in * 14 : nullptr;
@@ -585,8 +597,8 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             Axes ax = body_axes(t);
             float u[6], F[8];
             const bool very_first = first && (ks == 0);
-            if (very_first) pid6<false, false>(p, y, sp, pid, 0.f, 1e9f, nullptr, false, u);
-            else pid6<true, true>(p, y, sp, pid, h, 1.0f / h, inc_prev, ks > 0, u);
+            if (very_first) pid6<false, false>(p, y, sp, pid, 0.f, nullptr, nullptr, false, u);
+            else pid6<true, true>(p, y, sp, pid, half_dtp, kd_inv, inc_prev, ks > 0, u);
             float cvz[8];
             allocate6<SYM>(p, ax, u, F, cvz);
             if (aux_last) write_aux6(p, u, cvz, aux_last);
@@ -659,13 +671,13 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             {
                 // same arithmetic, same order of operations as below; y and acc live in LDS between the stages
                 park_y.put(y);
-                derivs6<SYM, FLOW, false, true>(p, y, tb, sp, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr);
+                derivs6<SYM, FLOW, false, true>(p, y, tb, sp, pid, 0.f, nullptr, dp, ks > 0, cur, k, nullptr);
                 park_a.put(k);
 #pragma unroll
                 for (int q = 0; q < 12; q++) yt[q] = fmaf(hh, k[q], y[q]);
 #pragma unroll
                 for (int q = 0; q < 6; q++) dp[q] = hh * k[q];
-                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, dp), sp, pid, hh, inv_hh, dp, true, cur, k, nullptr);
+                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, dp), sp, pid, half_dtp, kd_inv, dp, true, cur, k, nullptr);
                 float d2[6], d3[6], a[12], yb[12];
                 park_a.get(a);
 #pragma unroll
@@ -676,7 +688,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_y.get(yb);
 #pragma unroll
                 for (int q = 0; q < 12; q++) yt[q] = fmaf(hh, k[q], yb[q]);
-                derivs6<SYM, FLOW, false, true>(p, yt, stage_trig(tb, yt, d2), sp, pid, 0.f, 1e9f, dp, true, cur, k, nullptr);
+                derivs6<SYM, FLOW, false, true>(p, yt, stage_trig(tb, yt, d2), sp, pid, 0.f, nullptr, dp, true, cur, k, nullptr);
 #pragma unroll
                 for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
                 park_a.get(a);
@@ -686,7 +698,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_y.get(yb);
 #pragma unroll
                 for (int q = 0; q < 12; q++) yt[q] = fmaf(h, k[q], yb[q]);
-                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, d3), sp, pid, hh, inv_hh, dp, true, cur, k, aux_last);
+                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, d3), sp, pid, half_dtp, kd_inv, dp, true, cur, k, aux_last);
                 park_a.get(a);
                 park_y.get(yb);
 #pragma unroll
@@ -696,24 +708,24 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 continue;
             }
 #endif
-            derivs6<SYM, FLOW, false, true>(p, y, tb, sp, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr);
+            derivs6<SYM, FLOW, false, true>(p, y, tb, sp, pid, 0.f, nullptr, dp, ks > 0, cur, k, nullptr);
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
 #pragma unroll
             for (int q = 0; q < 6; q++) dp[q] = hh * k[q];                       // (y + hh k1) - y
-            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, dp), sp, pid, hh, inv_hh, dp, true, cur, k, nullptr);
+            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, dp), sp, pid, half_dtp, kd_inv, dp, true, cur, k, nullptr);
             float d2[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }  // hh (k2 - k1)
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
-            derivs6<SYM, FLOW, false, true>(p, yt, stage_trig(tb, yt, d2), sp, pid, 0.f, 1e9f, dp, true, cur, k, nullptr);
+            derivs6<SYM, FLOW, false, true>(p, yt, stage_trig(tb, yt, d2), sp, pid, 0.f, nullptr, dp, true, cur, k, nullptr);
             float d3[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }          // h k3 - hh k2
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
-            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, d3), sp, pid, hh, inv_hh, dp, true, cur, k, aux_last);
+            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, d3), sp, pid, half_dtp, kd_inv, dp, true, cur, k, aux_last);
 #pragma unroll
             for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (acc[q] + k[q]) - d3[q];            // y_new - (y + h k3)
         }

@@ -63,9 +63,12 @@ def rov6_dev_fields(p):
     sym = sym_layout(p.alloc, p.alloc_inv)
     sa, sb = sym if sym is not None else (np.zeros(8), np.zeros(8))
     k = p.thrust_k
+    ad, I = _a(p.added), _a(p.inertia)
+    sc = np.array([p.m * cg[2], p.m - ad[2], p.m - ad[1], p.m - ad[0], I[8] - I[4] + ad[4] - ad[5],
+                   I[0] - I[8] + ad[5] - ad[3], I[4] - I[0] + ad[3] - ad[4], 0.0])
     return [("m", p.m), ("wb", W - B), ("cg", cg), ("I", _a(p.inertia)),
             ("gw", cg * W - cb * B), ("added", _a(p.added)), ("minv", _a(p.minv)), ("dlin", _a(p.dlin)),
-            ("dquad", _a(p.dquad)), ("A", _a(p.alloc)), ("Ainv", _a(p.alloc_inv)), ("sym_a", sa), ("sym_ainv", sb),
+            ("dquad", _a(p.dquad)), ("A", _a(p.alloc)), ("Ainv", _a(p.alloc_inv)), ("sym_a", sa), ("sym_ainv", sb), ("sym_c", sc),
             ("thrust_k", k), ("inv_thrust_k", 1.0 / k), ("rpm_max", p.rpm_max), ("rpm_dead", p.rpm_deadband),
             ("f_max", k * (p.rpm_max / 60.) ** 2), ("f_dead", k * (p.rpm_deadband / 60.) ** 2),
             ("kp", _a(p.kp)), ("ki", _a(p.ki)), ("kd", _a(p.kd)), ("windup", _a(p.windup)), ("umax", _a(p.umax)),

@@ -248,8 +248,35 @@ void FN(orc_force_model6)(const mvrl_rov6_params* P, const real ang[3], const re
 }
 
 /* Everything of derivs after the controller (6DoF.py:424-442) for given rpm. cur_glob = (u_c, v_c) global. */
-static void rhs6_given_rpm(const mvrl_rov6_params* P, const real y[12], const real axes[9], const real rpm[8],
+/* Perturbation ensemble (tests only; tests/parity_util.ensemble_sensitive).  With noise > 0 the RK4 harness multiplies the
+ * state by 1 + noise * U(-1, 1) after every sub-step, the set-point once per step and every thruster's rpm at every RHS
+ * evaluation (the thrusters pull against each other: a force or moment can be a small difference of eight large terms, so
+ * a relative rounding of the terms is a much larger relative rounding of the sum - the one place where noise on the state
+ * alone would under-state what fp32 arithmetic does, in particular from rest).  A stand-in for the rounding an fp32
+ * implementation commits, used to ask whether the fp64 algorithm ITSELF is stable at fp32 resolution for a given env.
+ * Off (0) unless a test switches it on; every golden-vector check runs with it off. */
+static double FN(g_noise) = 0.0;
+static uint64_t FN(g_noise_seed) = 0;
+void FN(orc_set_noise)(double noise, uint64_t seed) { FN(g_noise) = noise; FN(g_noise_seed) = seed; }
+static __thread double FN(tl_noise) = 0.0;
+static __thread uint64_t FN(tl_rng) = 0;
+static double noise_u(uint64_t* st) {   /* splitmix64 -> U(-1, 1) */
+    uint64_t z = (*st += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+static const real* noisy_rpm(const real* rpm, int n, real* buf) {
+    if (!(FN(tl_noise) > 0)) return rpm;
+    for (int k = 0; k < n; k++) buf[k] = rpm[k] * (real)(1.0 + FN(tl_noise) * noise_u(&FN(tl_rng)));
+    return buf;
+}
+
+static void rhs6_given_rpm(const mvrl_rov6_params* P, const real y[12], const real axes[9], const real rpm_in[8],
                            const real cur_glob[2], real dy[12]) {
+    real rpm_buf[8];
+    const real* rpm = noisy_rpm(rpm_in, 8, rpm_buf);
     real cur_body[6] = {0, 0, 0, 0, 0, 0};
     if (cur_glob && (cur_glob[0] != 0 || cur_glob[1] != 0)) {
         real cg3[3] = {cur_glob[0], cur_glob[1], 0};
@@ -319,8 +346,10 @@ static void ctrl3(const mvrl_rov3_params* P, double t, const real y[6], const re
     }
 }
 
-static void rhs3_given_rpm(const mvrl_rov3_params* P, const real y[6], const real rpm[4], const real cur_glob[2],
+static void rhs3_given_rpm(const mvrl_rov3_params* P, const real y[6], const real rpm_in[4], const real cur_glob[2],
                            real dy[6]) {
+    real rpm_buf[4];
+    const real* rpm = noisy_rpm(rpm_in, 4, rpm_buf);
     real psi = y[2], u = y[3], v = y[4], r = y[5];
     real vel[3] = {u, v, r};
     real c = r_cos(psi), s = r_sin(psi);
@@ -439,6 +468,8 @@ static void integrate_rk4(rhs_ctx* c, double t0, double dt, int n_sub, real* y) 
         for (int i = 0; i < n; i++) yt[i] = y[i] + hh * k3[i];
         rhs_eval(c, tk + h, yt, k4);
         for (int i = 0; i < n; i++) y[i] = y[i] + (hh / 6) * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
+        if (FN(tl_noise) > 0)
+            for (int i = 0; i < n; i++) y[i] *= (real)(1.0 + FN(tl_noise) * noise_u(&FN(tl_rng)));
     }
 }
 
@@ -661,6 +692,11 @@ int FN(orc_rov_step)(int dof, const mvrl_rov6_params* p6, const mvrl_rov3_params
         memset(&c, 0, sizeof(c));
         c.dof = dof; c.zoh = (integrator == 0 && control_mode == MVRL_CTRL_ZOH); c.p6 = p6; c.p3 = p3; c.sp = spe;
         c.pid = &pid; c.cur = cur;
+        FN(tl_noise) = FN(g_noise);
+        if (FN(tl_noise) > 0) {
+            FN(tl_rng) = FN(g_noise_seed) ^ ((uint64_t)e * 0xd1342543de82ef95ull) ^ ((uint64_t)istep[e] << 40);
+            if (!fixed_sp) for (int i = 0; i < dof; i++) spe[i] *= (real)(1.0 + FN(tl_noise) * noise_u(&FN(tl_rng)));
+        }
         double t0 = time[e] - dt;
         if (margins_out) {
             for (int i = 0; i < ORC_N_MARGIN; i++) margins_out[e * ORC_N_MARGIN + i] = 1e300;
@@ -669,6 +705,7 @@ int FN(orc_rov_step)(int dof, const mvrl_rov6_params* p6, const mvrl_rov3_params
         if (integrator == 0) integrate_rk4(&c, t0, dt, n_sub, ye);
         else if (integrate_rk45(&c, t0, time[e], dt, 1e-3, 1e-3, ye) != 0) status = -1;
         FN(tl_margin) = 0;
+        FN(tl_noise) = 0.0;
         if (dof == 6) for (int i = 3; i < 6; i++) ye[i] = py_mod(ye[i], (real)TWO_PI); /* 6DoF.py:560 */
         else ye[2] = py_mod(ye[2], (real)TWO_PI);                                      /* 3DoF.py:480 */
         if (dof == 6) FN(orc_obs6)(p6, ye, path + e * npath, spe, obs + e * nobs);

@@ -245,6 +245,8 @@ class OracleRovEnv:
     def observe(self):
         return np.stack([self.o.obs_rov(self.dof, self.y[i], self.path[i], self.sp[i]) for i in range(self.n)])
 
+    noise, noise_seed = 0.0, 0   # > 0: perturbation-ensemble member (mvrl_oracle.c orc_set_noise); tests only
+
     def step(self, actions):
         o = self.o
         a = o.arr(actions, (self.n, self.dof))
@@ -257,6 +259,9 @@ class OracleRovEnv:
                       + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
                       + [C.c_void_p] * 7)
         fl = self.flow
+        setn = o._f("orc_set_noise")
+        setn.restype, setn.argtypes = None, [C.c_double, C.c_uint64]
+        setn(float(self.noise), int(self.noise_seed))
         st = f(self.dof, C.addressof(o.rov6), C.addressof(o.rov3), self.n, float(self.dt),
                0 if self.integrator == "rk4" else 1, int(self.n_sub), int(self.control_mode), int(self.fixed_sp),
                int(self.max_steps),
@@ -269,6 +274,7 @@ class OracleRovEnv:
                0.0 if fl is None else fl.dy, self.toffset.ctypes.data,
                obs.ctypes.data, rew.ctypes.data, done.ctypes.data, self.gcf.ctypes.data, self.rpm.ctypes.data,
                self.nfev.ctypes.data, self.margins.ctypes.data)
+        setn(0.0, 0)
         if st != 0:
             raise RuntimeError("oracle RK45: step size too small")
         return obs, rew, done

@@ -105,8 +105,66 @@ class OutlierAudit:
                          f"{NAMES[k]} at {self.margin_at_jump[i, k]:.2e} ({ratios[k]:.2f} x bound){'' if ex[i] else '   <-- UNEXPLAINED'}")
         return "\n".join(lines)
 
-    def assert_explained(self, max_share=None, max_smooth_share=0.002):
+    def assert_explained(self, max_share=None, max_smooth_share=0.002, resolver=None):
+        """resolver(lanes, jump_steps) -> bool[len(lanes)] (see `ensemble_sensitive`): second line of defence for envs whose
+        jump the distance bounds do not cover - the stated bounds are calibrated on ~1e6 env-steps, and about 1 jump in 100
+        happens a few bounds away (measured on 2.6e7 env-steps, tools/err_quantiles.py).  Such an env passes only if the fp64
+        reference itself, perturbed at fp32-rounding level, leaves its own unperturbed trajectory there."""
+        un = np.nonzero(self.unexplained())[0]
+        if len(un) and resolver is not None:
+            sens = np.asarray(resolver(un, self.first_jump[un]), bool)
+            self.resolved = int(sens.sum())
+            for i in un[sens]:
+                self.margin_at_jump[i] = 0.0          # counts as explained from here on
         assert not self.unexplained().any(), "envs that jumped off the fp64 trajectory without a discontinuity within fp32 reach:\n" + self.report()
         assert self.smooth().mean() <= max_smooth_share, self.report()
         if max_share is not None:
             assert self.bad.mean() <= max_share, self.report()
+
+
+# Relative size of the per-sub-step state perturbation of `ensemble_sensitive`.  fp32 storage of the state alone is 6e-8 (half an
+# ulp); the kernels round ~6000 operations per env step on top, and the deviation they accumulate is smooth and small: median
+# 2.0e-6, 99.99 % below 5e-6 after 25 steps (tools/err_quantiles.py, 1 048 576 envs).  The ensemble uses the level at which
+# its own median deviation matches that accepted typical deviation - not more.
+ENSEMBLE_NOISE = 1e-7
+
+
+def ensemble_sensitive(oracle_mod, dof, init, actions, lanes, until, env_kw=None, toffset=None, members=48, noise=ENSEMBLE_NOISE,
+                       seed=1, return_median=False):
+    """Is the fp64 REFERENCE itself unstable at fp32 resolution for these envs?  For each lane, `members` fp64 oracle runs of
+    the same env whose state is multiplied by 1 + noise * U(-1, 1) after every RK4 sub-step (and the set-point once per step;
+    mvrl_oracle.c orc_set_noise) are compared with the unperturbed fp64 run: the lane is sensitive if a member is more than
+    SMOOTH_TOL away at or before step until[lane].  An env for which that holds cannot be followed to 1e-5 by any fp32
+    implementation - whichever discontinuity is responsible."""
+    lanes, until = np.asarray(lanes), np.asarray(until)
+    L = len(lanes)
+    if L == 0:
+        return (np.zeros(0, bool), 0.0) if return_median else np.zeros(0, bool)
+    env_kw = dict(env_kw or {})
+    rows = np.tile(np.arange(L), members)
+    init = np.asarray(init, np.float64)[lanes]
+    toff = None if toffset is None else np.asarray(toffset, np.float64)[lanes]
+    ref = oracle_mod.OracleRovEnv(dof, L, "f64", max_steps=10 ** 9, **env_kw)
+    ens = oracle_mod.OracleRovEnv(dof, L * members, "f64", max_steps=10 ** 9, **env_kw)
+    ref.reset(init, toffset=toff)
+    ens.reset(init[rows], toffset=None if toff is None else toff[rows])
+    ens.noise, ens.noise_seed = float(noise), int(seed)
+    ang = [3, 4, 5] if dof == 6 else [2]
+    sens = np.zeros(L, bool)
+    med = 0.0
+    for s in range(min(int(until.max()) + 1, len(actions))):
+        a = np.asarray(actions[s], np.float64)[lanes]
+        ref.step(a)
+        ens.step(a[rows])
+        r = np.tile(ref.y, (members, 1))
+        d = np.abs(ens.y - r)
+        d[:, ang] = np.minimum(d[:, ang], np.abs(d[:, ang] - 2 * np.pi))
+        e = (d / np.maximum(1.0, np.abs(r))).max(axis=1).reshape(members, L)
+        sens |= (e > SMOOTH_TOL).any(axis=0) & (s <= until)
+        med = max(med, float(np.median(e)))
+    return (sens, med) if return_median else sens
+
+
+def make_resolver(oracle_mod, dof, init, actions, env_kw=None, toffset=None):
+    """resolver for OutlierAudit.assert_explained: the perturbation ensemble on the run's own inputs."""
+    return lambda lanes, steps: ensemble_sensitive(oracle_mod, dof, init, actions, lanes, steps, env_kw, toffset)

@@ -180,7 +180,10 @@ def test_benched_c4_instance_at_full_size_vs_oracle(oracle_mod):
         assert np.max(np.abs(o - ref_obs)[on]) < 2e-5, k
         assert not done.any().item() and not ref_done.any()
     print("C4 at full size: " + audit.report())
-    audit.assert_explained(max_share=0.004, max_smooth_share=0.002)
+    from .parity_util import make_resolver
+    audit.assert_explained(max_share=0.004, max_smooth_share=0.002,
+                           resolver=make_resolver(oracle_mod, 6, init, [acts[k % 8] for k in range(steps)], dict(n_substeps=4, flow=ref.flow),
+                                                  toffset=toff))
     assert torch.isfinite(obs).all().item()
     env.close()
 

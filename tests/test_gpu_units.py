@@ -173,7 +173,7 @@ def test_force_model_golden(precision, tol, flavour):
     g = golden("g07_force_model.npz")
     # constants moved by less than the tolerance, enough to leave the baked / sparse classes
     over = {"baked": {}, "sym": dict(rov6=P.rov6_params(Xu=-4.03 * (1 + (1e-13 if precision == "f64" else 2e-7)))),
-            "generic": dict(rov6=P.rov6_params(Yr=1e-12))}[flavour]
+            "generic": dict(rov6=P.rov6_params(Yr=5e-12))}[flavour]
     h = _lib.Handle(P.make_config("rov6", 1, use_flow=False, precision=precision, **over))
     assert flavour in h.variant, h.variant
     r = h.vehicle_ops(g["angles"], rpm=g["rpm"], vel=g["vel"], want=("rhs", "thruster_h"))
