@@ -276,27 +276,28 @@ __device__ __forceinline__ Trig6 trig6(const float* y) {
     return t;
 }
 
-// sin/cos of the attitude at an RK stage whose angles differ from the sub-step's base angles by the small, known
-// increments d[3..5] (= c * k of the previous stage): rotate the base values by (cos d, sin d) from the [-pi/4, pi/4]
-// polynomials of sincos_f32 - no range reduction, no quadrant selection: 14 instructions per angle instead of ~35, three
-// of the four stages of every sub-step.  |d| <= pi/4 is checked per lane (the vehicle turns at < 5 rad/s, d = h * rate
-// ~ 0.1); a lane with a larger increment, and the fp64 build (whose parity bar is 1e-9), evaluate the stage in full.
+// sin/cos of the attitude at an RK stage whose angles differ from known ones (the sub-step's base attitude) by the small,
+// known increments d[3..5] (= c * k of the previous stage): rotate the base values by (cos d, sin d) from short Taylor
+// polynomials - no range reduction, no quadrant selection: 12 instructions per angle instead of ~28, three of the four
+// stages of every sub-step, and the base attitude of every sub-step after the first (rotated by the sub-step's own
+// increment).  |d| <= 0.25 is checked per lane (truncation: 1.2e-8 in sin d, 4e-10 in cos d; the vehicle turns at < 3 rad/s,
+// d = h * rate < 0.15); a lane with a larger increment, and the fp64 build (whose parity bar is 1e-9), evaluate in full.
 __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, const float* d) {
 #if MVRL_F64 || defined(MVRL_FULL_STAGE_TRIG)
     return trig6(yt);
 #else
     const float m = fmaxf(fmaxf(fabsf(d[3]), fabsf(d[4])), fabsf(d[5]));
 #ifdef MVRL_TRIG_WAVE_FALLBACK
-    if (__builtin_expect(__any(m > 0.78f), 0)) return trig6(yt);   // the whole wave evaluates the stage in full
+    if (__builtin_expect(__any(m > 0.25f), 0)) return trig6(yt);   // the whole wave evaluates the stage in full
 #endif
     Trig6 t;
     float sd[3], cd[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float r = d[3 + k], r2 = r * r;
-        const float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+        const float ps = fmaf(8.333333333e-3f, r2, -1.666666667e-1f);          // sin r = r + r^3 (-1/6 + r^2 / 120)
         sd[k] = fmaf(ps * r2, r, r);
-        const float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+        const float pc = fmaf(-1.388888889e-3f, r2, 4.166666667e-2f);          // cos r = 1 - r^2 / 2 + r^4 (1/24 - r^2 / 720)
         cd[k] = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
     }
     t.sph = fmaf(b.cph, sd[0], b.sph * cd[0]); t.cph = fmaf(-b.sph, sd[0], b.cph * cd[0]);
@@ -307,7 +308,7 @@ __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, con
     // take the full evaluation as a DIVERGENT branch: the wave issues those ~80 instructions with one or two lanes enabled.
     // The chip runs this kernel at its power limit, where an instruction's cost is the lanes it
     // switches, not its issue slot - cheaper than sending all 64 lanes through the full evaluation whenever one needs it.
-    if (m > 0.78f) t = trig6(yt);
+    if (m > 0.25f) t = trig6(yt);
 #endif
     return t;
 #endif
@@ -567,6 +568,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     // pose increment between the last PID call of a sub-step and the first of the next; not known across env steps
     // (new set-point, angle wrap): the first call of a step uses the rounded difference (inc_valid = false)
     float inc_prev[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    Trig6 tb = {0.f, 1.f, 0.f, 1.f, 0.f, 1.f};   // FAITHFUL: base attitude of the current sub-step
 #ifdef MVRL_STAMP_ON
     {   // everything the loop needs has arrived
         float dep = y[0] + y[11] + pid.eint[5] + pid.eold[5] + sp[5] + cur.x;
@@ -590,6 +592,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
 #endif
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[12], acc[12], yt[12];
+        float tb_inc[3] = {0.f, 0.f, 0.f};
         float* const aux_last = (ks == io.n_sub - 1) ? aux_row : nullptr;
         if (ZOH) {
             // PID + allocation once per sub-step; t - tOld = h except for the very first call after reset (= 0)
@@ -666,7 +669,9 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             float dp[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) dp[q] = inc_prev[q];
-            const Trig6 tb = trig6(y);  // the sub-step's base attitude: the three later stages rotate it (stage_trig)
+            // the sub-step's base attitude: the three later stages rotate it (stage_trig), and so does the next sub-step
+            // (re-anchored by a full evaluation at the first sub-step of an env step and every fourth one after it)
+            if ((ks & 3) == 0) tb = trig6(y);
 #ifdef MVRL_PARK_ON
             {
                 // same arithmetic, same order of operations as below; y and acc live in LDS between the stages
@@ -702,9 +707,10 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_a.get(a);
                 park_y.get(yb);
 #pragma unroll
-                for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (a[q] + k[q]) - d3[q];
+                for (int q = 0; q < 6; q++) { d2[q] = h6 * (a[q] + k[q]); inc_prev[q] = d2[q] - d3[q]; }
 #pragma unroll
                 for (int q = 0; q < 12; q++) y[q] = fmaf(h6, a[q] + k[q], yb[q]);
+                if (((ks + 1) & 3) != 0 && ks + 1 < io.n_sub) tb = stage_trig(tb, y, d2);
                 continue;
             }
 #endif
@@ -727,10 +733,15 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
             derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, d3), sp, pid, half_dtp, kd_inv, dp, true, cur, k, aux_last);
 #pragma unroll
-            for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (acc[q] + k[q]) - d3[q];            // y_new - (y + h k3)
+            for (int q = 0; q < 6; q++) { d2[q] = h6 * (acc[q] + k[q]); inc_prev[q] = d2[q] - d3[q]; }   // y_new - (y + h k3)
+            tb_inc[0] = d2[3]; tb_inc[1] = d2[4]; tb_inc[2] = d2[5];
         }
 #pragma unroll
         for (int q = 0; q < 12; q++) y[q] = fmaf(h6, acc[q] + k[q], y[q]);
+        if (!ZOH && ((ks + 1) & 3) != 0 && ks + 1 < io.n_sub) {
+            const float dd[6] = {0.f, 0.f, 0.f, tb_inc[0], tb_inc[1], tb_inc[2]};
+            tb = stage_trig(tb, y, dd);
+        }
     }
 #ifdef MVRL_STAMP_ON
     asm volatile("" : "+v"(y[0]), "+v"(y[11]));
