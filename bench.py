@@ -126,6 +126,8 @@ def main():
                     help="6-DoF kernel flavour: the reference's constants (literals), the reference's vehicle with a retuned "
                          "controller (vehicle literals + run-time PID numbers), other BlueROV2-structured numbers "
                          "(run-time constants, sparse forms), or arbitrary constants (dense 6 x 6 forms)")
+    ap.add_argument("--specialize", action="store_true",
+                    help="with --flavour ctrl|sym|generic: compile the step kernel for those constants at start-up (mvrl_specialize, hiprtc)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=12345)
     args = ap.parse_args()
@@ -176,7 +178,7 @@ def main():
               "generic": lambda: P_.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3, m=12.0)}[args.flavour]()
     env = MarineVecEnv(wl["model"], n, seed=args.seed, n_substeps=args.n_substeps, control_mode=args.control_mode,
                        flow=flow, device=local_rank, env_offset=rank * n, infos="lean", precision=args.precision,
-                       vehicle_params=vp)
+                       vehicle_params=vp, specialize=args.specialize and (vp is not None or bool(os.environ.get("MVRL_JIT_FORCE"))))
     act_dim, obs_dim = env.action_space.shape[0], env.observation_space.shape[0]
     h = env.handle
     stream = torch.cuda.current_stream().cuda_stream

@@ -272,6 +272,17 @@ int mvrl_derivs(mvrl_handle* h, int64_t n, const float* t, const float* y, const
 int mvrl_derivs_f64(mvrl_handle* h, int64_t n, const double* t, const double* y, const double* sp, double* eold, double* eint,
                     double* told, const uint8_t* has_old, double* dy, double* gcf, double* rpm);
 
+/* ---- run-time specialisation (6-DoF, fp32, RK4 harness).  libmvrl.so carries its fastest step kernel - model constants
+ * as instruction literals - for the reference's default vehicle only (6DoF.py:83-218); a vehicle with other constants
+ * (the reference is edited or subclassed for that) runs kernels that read them at run time, 1.15x (same structure) to 1.8x
+ * (arbitrary constants) slower.  mvrl_specialize compiles the step kernel once more, with hiprtc, for THIS handle's
+ * constants (about a second) and switches the handle to it: same arithmetic, same arguments, mvrl_variant() gains "jit-".
+ * No-op for handles that already run the literal-constant kernel.  Fails with MVRL_EHIP and the compiler log in
+ * mvrl_last_error when hiprtc is unavailable; the handle then keeps its ahead-of-time kernel.
+ * mvrl_jit_compile_check performs the compilation alone (no GPU, nothing loaded): build and CI check. ---- */
+int mvrl_specialize(mvrl_handle* h);
+int mvrl_jit_compile_check(const mvrl_rov6_params* params, int control_mode, size_t* code_size, char* log_buf, size_t log_cap);
+
 /* ---- unit-level operators of the 6-DoF vehicle for n independent tuples (host arrays; NULL inputs / outputs are skipped), each
  * evaluated by the device functions the step kernel runs - the public methods example_trialTrajectories.py:100-134 and the
  * demos call on the vehicle object:

@@ -28,7 +28,7 @@ SYMBOLS = [
     "mvrl_dev_upload", "mvrl_dev_download", "mvrl_synchronize",
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
-    "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64", "mvrl_vehicle_ops", "mvrl_vehicle_ops_f64",
+    "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64", "mvrl_vehicle_ops", "mvrl_vehicle_ops_f64", "mvrl_specialize", "mvrl_jit_compile_check",
     "mvrl_auv_pd_episodes_dev", "mvrl_rollout_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
@@ -105,6 +105,8 @@ def load(path=None):
     lib.mvrl_derivs.argtypes = [vp, i64] + [vp] * 10
     lib.mvrl_derivs_f64.argtypes = [vp, i64] + [vp] * 10
     lib.mvrl_vehicle_ops.argtypes = [vp, i64] + [vp] * 8
+    lib.mvrl_specialize.argtypes = [vp]
+    lib.mvrl_jit_compile_check.argtypes = [vp, C.c_int, vp, vp, C.c_size_t]
     lib.mvrl_vehicle_ops_f64.argtypes = [vp, i64] + [vp] * 8
     lib.mvrl_rollout_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.mvrl_auv_pd_episodes_dev.argtypes = [vp, vp, vp, C.c_double, i32, vp, vp, vp]
@@ -298,6 +300,11 @@ class Handle:
         check(self._fn("mvrl_vehicle_ops")(self.h, n, ang.ctypes.data, p(g), p(r), p(v), p(out.get("axes")), p(out.get("rpm")),
                                            p(out.get("rhs")), p(out.get("thruster_h"))), self.h)
         return out
+
+    def specialize(self):
+        """Compile the 6-DoF step kernel for this handle's constants (hiprtc) and switch to it (mvrl_specialize)."""
+        check(self.lib.mvrl_specialize(self.h), self.h)
+        return self.variant
 
     def enable_aux(self, on=True):
         check(self.lib.mvrl_enable_aux(self.h, 1 if on else 0), self.h)

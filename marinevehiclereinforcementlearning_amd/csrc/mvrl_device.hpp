@@ -4,10 +4,26 @@
 // (plane k of env i at base[k * n + i]) so that every state load/store of a wave is one fully coalesced
 // 256-B transaction; model constants are wave-uniform kernel arguments (scalar loads -> SGPRs).
 #pragma once
+#ifndef __HIPCC_RTC__   /* hiprtc brings its own runtime declarations and fixed-width types */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
-#include <type_traits>
+#else
+using __hip_internal::uint8_t;
+using __hip_internal::int32_t;
+using __hip_internal::uint32_t;
+using __hip_internal::int64_t;
+using __hip_internal::uint64_t;
+typedef unsigned long uintptr_t;
+#ifndef offsetof
+#define offsetof(t, m) __builtin_offsetof(t, m)
+#endif
+#endif
+
+namespace mvrl {
+template <class A, class B> struct same_type { static constexpr bool value = false; };
+template <class A> struct same_type<A, A> { static constexpr bool value = true; };
+}  // namespace mvrl
 
 #define MVRL_BLOCK 256
 // Launch bounds of the rigid-body step kernels.  The second argument (min waves per SIMD) caps the register
@@ -294,9 +310,9 @@ __device__ __forceinline__ const Rov6Baked* launder_after(const Rov6Baked* p, fl
 __device__ __forceinline__ const Rov3Baked* launder(const Rov3Baked* p) { return p; }
 template <class PP, class T>
 __device__ __forceinline__ PP param_ptr(const T* pg) {
-    if constexpr (std::is_same<PP, const Rov6Baked*>::value || std::is_same<PP, const Rov3Baked*>::value) {
+    if constexpr (same_type<PP, const Rov6Baked*>::value || same_type<PP, const Rov3Baked*>::value) {
         return nullptr;  // never dereferenced: every member is static
-    } else if constexpr (std::is_same<PP, CPV6>::value) {
+    } else if constexpr (same_type<PP, CPV6>::value) {
         return (PP)(uintptr_t)(&pg->kp[0]);
     } else {
         return (PP)(uintptr_t)pg;

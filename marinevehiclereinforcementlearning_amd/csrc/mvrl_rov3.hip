@@ -32,10 +32,11 @@ __device__ __forceinline__ void control3(PP p, const float* y, const float* sp, 
             const bool use = (i < 2) ? inc_valid : (inc_valid && fabsf(de - di) <= 1e-5f);
             de = use ? di : de;
         }
-        float dedt = de * inv_den;
-        if (HAS_DT) s.eint[i] = fmaf(0.5f * (s.eold[i] + e[i]), dtp, s.eint[i]);
+        // dtp / 2 and K_D / dt are the same for every call of a step: loop-invariant products (literals x one register in the
+        // baked flavour), hoisted by the compiler
+        if (HAS_DT) s.eint[i] = fmaf(s.eold[i] + e[i], 0.5f * dtp, s.eint[i]);
         s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
-        float v = fmaf(p->ki[i], s.eint[i], fmaf(p->kd[i], dedt, p->kp[i] * e[i]));
+        float v = fmaf(p->ki[i], s.eint[i], fmaf(p->kd[i] * inv_den, de, p->kp[i] * e[i]));
         u[i] = clampf(v, -p->umax[i], p->umax[i]);
         s.eold[i] = e[i];
     }

@@ -7,7 +7,11 @@
 // One lane = one env; state is read once and written once per step (SoA planes, coalesced); everything
 // between lives in VGPRs.  The kernel is VALU-bound (~7 k lane-ops per env step against 300 B of traffic), so
 // the work here is instruction count, not bytes - see DESIGN.md.
+#ifdef MVRL_JIT   /* run-time specialisation (mvrl_specialize): device code only, constants from mvrl_jit_consts.inc */
+#include "mvrl_device.hpp"
+#else
 #include "mvrl_kernels.hpp"
+#endif
 #if MVRL_F64
 #include "mvrl_rk45.hpp"
 #endif
@@ -445,7 +449,11 @@ __device__ unsigned long long g_stamp_rt[5 * MVRL_STAMP_WAVES];   // s_memrealti
 // (tools/valu_dep.hip).  33 LDS instructions per sub-step against ~1450 VALU.
 #if !MVRL_F64 && !defined(MVRL_NO_PARK)
 #define MVRL_PARK_ON 1
+#ifdef MVRL_JIT_MIN_WAVES   /* mvrl_specialize: literal constants need no SGPR headroom; the dense form is tried at 4 waves first */
+#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, MVRL_JIT_MIN_WAVES)
+#else
 #define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, SYM ? 4 : 2)
+#endif
 // LDS per block = 10 KB although the parked tiles need 6: 160 KB / 10 KB = 16 one-wave blocks per CU = exactly four waves
 // per SIMD.  A kernel instance that happens to need <= 96 VGPRs would otherwise get a FIFTH wave, and five waves rotate
 // over eight issue slots (tools/valu_dep.hip).
@@ -814,6 +822,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     }  // kstep
 }
 
+#ifndef MVRL_JIT   /* everything below is built ahead of time only */
 #ifdef MVRL_STAMP_ON
 extern "C" int mvrl_debug_stamps(unsigned long long* dst, size_t n_words) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamp), n_words * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
@@ -1027,4 +1036,5 @@ hipError_t launch_rov6_reset(const Rov6Dev* p, float* state, int64_t n, const ui
     return hipGetLastError();
 }
 
+#endif  // !MVRL_JIT
 }  // namespace mvrl

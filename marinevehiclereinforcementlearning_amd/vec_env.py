@@ -62,7 +62,10 @@ class MarineVecEnv:
     model: "rov6" | "rov3" | "auv" | "auv_cyl".  Remaining keyword arguments mirror the reference constructors
     (`dt`, `maxSteps` - 6DoF.py:446 / 3DoF.py:376; `noiseMagCoeffs`, `noiseMagActuation`, `currentVelScale`,
     `currentTurbScale`, `stopOnBoundsExceeded` - verySimpleAuv.py:77-78) plus the integrator settings that are
-    this build's (`n_substeps`, `control_mode`).
+    this build's (`n_substeps`, `control_mode`).  `specialize=True` (6-DoF with `vehicle_params` other than the
+    reference's): compile the step kernel for those constants at construction (hiprtc, about a second; mvrl_specialize);
+    `specialize="auto"` does so only where it pays on today's runtime - arbitrary constants (the `generic` flavour: -23 % per
+    step; structured constants break even).
     """
 
     metadata = {"render.modes": []}
@@ -70,7 +73,7 @@ class MarineVecEnv:
     def __init__(self, model, num_envs, *, seed=0, dt=None, maxSteps=250, n_substeps=4, control_mode="faithful",
                  fixed_setpoint=False, flow=None, currentVelScale=1.0, currentTurbScale=2.0, noiseMagCoeffs=0.0,
                  noiseMagActuation=0.0, stopOnBoundsExceeded=True, device=0, env_offset=0, infos="dict",
-                 vehicle_params=None, precision="f32", integrator="rk4", report_truncation=False):
+                 vehicle_params=None, precision="f32", integrator="rk4", report_truncation=False, specialize=False):
         cyl = model == "auv_cyl"          # AuvEnvCyl: AuvEnv with way-points (tag/verySimpleAuv_cyl.py)
         if cyl:
             model = "auv"
@@ -98,6 +101,8 @@ class MarineVecEnv:
                                  integrator=integrator, **kw)
         self.dt = self.cfg.dt
         self._h = _lib.Handle(self.cfg)
+        if specialize is True or (specialize == "auto" and "/generic/" in self._h.variant and precision == "f32" and integrator == "rk4"):
+            self._h.specialize()
         self.flow = flow
         if use_flow:
             if self.model == P.MODEL_AUV:

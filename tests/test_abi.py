@@ -98,3 +98,19 @@ def test_baked_table_matches_params():
     assert not D.rov6_structured(P.rov6_params(l_x=0.15, l_y=0.101, Yr=0.3))
     sa, sb = D.sym_layout(P.rov6_params().alloc, P.rov6_params().alloc_inv)
     assert abs(sa[0] - 0.838671) < 1e-6 and abs(sb[7] - 2.083333) < 1e-6
+
+
+def test_jit_specialisation_compiles_without_a_gpu():
+    """mvrl_specialize's compilation step (hiprtc, gfx950) for the default, a BlueROV2-structured and an arbitrary set of
+    constants, both controller placements: the library carries its own kernel sources and they build at run time."""
+    import ctypes as C
+    from marinevehiclereinforcementlearning_amd import _lib, params as P
+    lib = _lib.load()
+    cases = [(P.rov6_params(), P.CTRL_FAITHFUL, "Lb1ELb0E"), (P.rov6_params(m=12.0, Xuu=-19.0), P.CTRL_ZOH, "Lb1ELb1E"),
+             (P.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3, m=12.0), P.CTRL_FAITHFUL, "Lb0ELb0E")]
+    for p6, mode, tag in cases:
+        size, log = C.c_size_t(0), C.create_string_buffer(8192)
+        rc = lib.mvrl_jit_compile_check(C.addressof(p6), mode, C.addressof(size), log, len(log))
+        assert rc == 0, log.value.decode()
+        names = log.value.decode().split("\n")
+        assert size.value > 10000 and len(names) == 2 and all("rov6_step_kernel" in nm and tag in nm for nm in names), names

@@ -182,6 +182,81 @@ def test_generic_kernel_with_modified_constants(oracle_mod):
         x.close()
 
 
+def test_specialised_kernels_for_non_default_constants(oracle_mod):
+    """mvrl_specialize: the step kernel compiled at run time (hiprtc) with the handle's own constants as literals - arbitrary
+    constants (dense form), BlueROV2-structured ones and a retuned controller, FAITHFUL and ZOH, with and without the
+    turbulence composition - against the fp64 oracle with the same constants, like the ahead-of-time flavours above; K-step
+    roll-outs and lane-range launches go through the same compiled function."""
+    over = dict(CG=[0.01, -0.015, 0.04], Yr=-0.3, Kv=-0.05, Nvv=-0.4, l_x=0.15, m=12.1, Xuu=-20.0,
+                I=[[0.17, 0.002, 0.0], [0.002, 0.15, 0.001], [0.0, 0.001, 0.16]])
+    cases = [("generic", P.rov6_params(**over), P.CTRL_FAITHFUL), ("sym", P.rov6_params(m=12.0, Xuu=-19.0, K_P=[20., 25., 25., 8., 10., 1.2]), P.CTRL_FAITHFUL),
+             ("ctrl", P.rov6_params(K_P=[20., 25., 30., 8., 10., 1.2], K_D=[18., 20., 22., 5., 4., 0.7]), P.CTRL_ZOH)]
+    n, steps = 1024, 20
+    init, actions = random_rov_batch(6, n, steps, 5)
+    for flavour, p6, mode in cases:
+        h = _lib.Handle(P.make_config("rov6", n, control_mode=mode, auto_reset=False, max_steps=10 ** 9, use_flow=False, rov6=p6))
+        assert flavour in h.variant and "jit" not in h.variant
+        h.reset(init=init)
+        for s in range(3):
+            h.step(actions[s])
+        y_aot = h.get_state()[:12].copy()
+        assert f"jit-{flavour}" in h.specialize() and h.specialize() == h.variant        # idempotent
+        h.reset(init=init)
+        for s in range(3):
+            h.step(actions[s])
+        # same arithmetic, other instruction selection: agreement far inside the parity tolerance for the typical env
+        d = np.abs(h.get_state()[:12] - y_aot)
+        assert np.median(d.max(axis=0)) < 2e-6, np.median(d.max(axis=0))
+        _audited_run(oracle_mod, 6, h, n, steps, init, actions, rov6=p6, control_mode=mode)
+        h.close()
+    # default constants: nothing to do; other models and precisions: refused
+    hb = _lib.Handle(P.make_config("rov6", 64, use_flow=False))
+    assert hb.specialize() == hb.variant and "baked" in hb.variant
+    hb.close()
+    for kw in (dict(model="rov3"), dict(model="rov6", precision="f64")):
+        hx = _lib.Handle(P.make_config(kw.pop("model"), 64, use_flow=False, **kw))
+        with pytest.raises(_lib.MvrlError):
+            hx.specialize()
+        hx.close()
+
+
+def test_specialised_kernel_through_vec_env_with_turbulence_chains_and_rollouts():
+    """MarineVecEnv(specialize=True) with the turbulence table: lane-range chains and K-step roll-outs of the run-time compiled
+    kernel are bit-identical to its whole-batch single steps (one function serves all three), auto-resets included."""
+    import torch
+    from marinevehiclereinforcementlearning_amd.chains import ChainStepper
+    from marinevehiclereinforcementlearning_amd.flow import ReconstructedFlow
+    from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
+    n, steps = 4096 + 64, 12
+    p6 = P.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3, m=12.0)
+
+    def mk():
+        f = ReconstructedFlow.synthetic(n_modes=4, n_time=64)
+        f.scale(11., 1., 2., translate=(-1.65, -1.1))
+        return MarineVecEnv("rov6", n, seed=4, maxSteps=5, flow=f, infos="lean", vehicle_params=p6, specialize=True)
+    ea, eb, ec = mk(), mk(), mk()
+    assert ea.variant == "rov6/jit-generic/faithful+flow"
+    acts = torch.rand((steps, n, 6), device="cuda") * 2 - 1
+    for e in (ea, eb, ec):
+        e.reset_tensors()
+    outs = [tuple(t.clone() for t in ea.step_tensors(acts[k])) for k in range(steps)]
+    st = ChainStepper(eb, n_chains=2)
+    st.fork()
+    bufs = [tuple(torch.empty_like(t) for t in outs[0]) for _ in range(steps)]
+    for k in range(steps):
+        st.step(acts[k], out=bufs[k])
+    st.join()
+    torch.cuda.synchronize()
+    ro = ec.rollout_tensors(acts)
+    for k in range(steps):
+        for ta, tb, tc in zip(outs[k], bufs[k], (ro[0][k], ro[1][k], ro[2][k])):
+            assert torch.equal(ta, tb) and torch.equal(ta, tc), k
+    assert np.array_equal(ea.get_state(), eb.get_state()) and np.array_equal(ea.get_state(), ec.get_state())
+    assert int(ea.handle.episode_counter().max()) >= 2
+    for e in (ea, eb, ec):
+        e.close()
+
+
 # ---- turbulence field + AuvEnv ---------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def base_flow():

@@ -88,3 +88,41 @@ def test_config1_3dof_1000_random_steps(oracle_mod):
     same_calls = float(np.mean(nfev == g["ncalls"]))
     assert err["state"] < 1e-7, (err, same_calls)
     assert same_calls > 0.999, same_calls
+
+
+def test_perturbation_ensemble_facility(oracle_mod):
+    """The oracle's test-only noise switch (orc_set_noise, tests/parity_util.ensemble_sensitive): off by default and after
+    every step (two identical runs stay bit-identical, so every golden check above runs on the unperturbed algorithm); on,
+    members differ from the plain run by a smooth deviation of the size of the noise times the loop's amplification, the same
+    seed reproduces the same member, and envs the distance bounds flag are the ones the ensemble finds sensitive."""
+    from .parity_util import ensemble_sensitive, ENSEMBLE_NOISE, F32_BOUNDS
+    rng = np.random.default_rng(5)
+    n, steps = 256, 12
+    init = np.concatenate([(rng.random((n, 6)) - 0.5) * 10, rng.random((n, 3)) * 2 * np.pi], axis=1)
+    acts = rng.uniform(-1, 1, size=(steps, n, 6))
+
+    def run(noise=0.0, seed=0):
+        env = oracle_mod.OracleRovEnv(6, n, "f64", max_steps=10 ** 9)
+        env.reset(init)
+        env.noise, env.noise_seed = noise, seed
+        for s in range(steps):
+            env.step(acts[s])
+        return env.y.copy()
+    y0, y0b = run(), run()
+    assert np.array_equal(y0, y0b)
+    y1, y1b, y2 = run(ENSEMBLE_NOISE, 3), run(ENSEMBLE_NOISE, 3), run(ENSEMBLE_NOISE, 4)
+    assert np.array_equal(y1, y1b) and not np.array_equal(y1, y2)
+    assert np.array_equal(run(), y0)                                  # the switch does not stick
+    dev = np.abs(y1 - y0).max(axis=1)
+    assert 1e-8 < np.median(dev) < 1e-5, np.median(dev)               # smooth and small for the typical env
+    # envs that stay far from every discontinuity are not sensitive; the ensemble flags a small minority
+    lanes = np.arange(n)
+    sens, med = ensemble_sensitive(oracle_mod, 6, init, acts, lanes, np.full(n, steps - 1), members=8, return_median=True)
+    assert med < 1e-5 and sens.mean() < 0.2, (med, sens.mean())
+    env = oracle_mod.OracleRovEnv(6, n, "f64", max_steps=10 ** 9)
+    env.reset(init)
+    near = np.zeros(n, bool)
+    for s in range(steps):
+        env.step(acts[s])
+        near |= (env.margins < 30 * np.asarray(F32_BOUNDS)).any(axis=1)
+    assert not (sens & ~near).any()                                    # sensitive envs all passed near a discontinuity
