@@ -822,6 +822,12 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     }  // kstep
 }
 
+#ifdef MVRL_JIT
+// The two instances mvrl_specialize loads, by explicit instantiation: hiprtc's name-expression mechanism would add a
+// writable table of kernel addresses to the code object (its only global variable).
+template __global__ void rov6_step_kernel<const Rov6Baked*, MVRL_JIT_SYM, MVRL_JIT_ZOH, false, 0, true>(const Rov6Dev*, const StepIO, const FlowDev);
+template __global__ void rov6_step_kernel<const Rov6Baked*, MVRL_JIT_SYM, MVRL_JIT_ZOH, true, 0, true>(const Rov6Dev*, const StepIO, const FlowDev);
+#endif
 #ifndef MVRL_JIT   /* everything below is built ahead of time only */
 #ifdef MVRL_STAMP_ON
 extern "C" int mvrl_debug_stamps(unsigned long long* dst, size_t n_words) {
