@@ -2,7 +2,7 @@
 """Distribution of the fp32-vs-fp64 trajectory error of the 6-DoF step kernel (GPU box): per-env maximum scaled error over a
 seeded random-action run, as quantiles, plus the drift / jump split of tests/parity_util.OutlierAudit.  Used to compare
 kernel revisions (MVRL_LIB selects the library): a change that only re-orders roundings must leave the quantiles where
-they were.   python tools/err_quantiles.py [n] [steps] [n_sub] [mode]"""
+they were.   python tools/err_quantiles.py [n] [steps] [n_sub] [mode] [dof]"""
 import os
 import sys
 
@@ -21,9 +21,9 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 25
     n_sub = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     mode = int(sys.argv[4]) if len(sys.argv) > 4 else P.CTRL_FAITHFUL
-    dof = 6
+    dof = int(sys.argv[5]) if len(sys.argv) > 5 else 6
     init, actions = random_rov_batch(dof, n, steps, 77 + dof)
-    h = _lib.Handle(P.make_config("rov6", n, n_substeps=n_sub, control_mode=mode, auto_reset=False, max_steps=10 ** 9, use_flow=False))
+    h = _lib.Handle(P.make_config("rov6" if dof == 6 else "rov3", n, n_substeps=n_sub, control_mode=mode, auto_reset=False, max_steps=10 ** 9, use_flow=False))
     env = oracle_mod.OracleRovEnv(dof, n, "f64", n_substeps=n_sub, control_mode=mode, max_steps=10 ** 9)
     env.reset(init.astype(np.float64))
     h.reset(init=init)
@@ -31,7 +31,7 @@ def main():
     for s in range(steps):
         env.step(actions[s].astype(np.float64))
         h.step(actions[s])
-        audit.update(circ_err(h.get_state()[:12].T, env.y, [3, 4, 5]).max(axis=1), env.margins)
+        audit.update(circ_err(h.get_state()[:2 * dof].T, env.y, [3, 4, 5] if dof == 6 else [2]).max(axis=1), env.margins)
     e = audit.max_err
     calm = e[~audit.jumped]
     q = np.quantile(calm, [0.5, 0.9, 0.99, 0.999, 0.9999])
