@@ -274,12 +274,16 @@ int mvrl_derivs_f64(mvrl_handle* h, int64_t n, const double* t, const double* y,
 
 /* ---- run-time specialisation (6-DoF, fp32, RK4 harness).  libmvrl.so carries its fastest step kernel - model constants
  * as instruction literals - for the reference's default vehicle only (6DoF.py:83-218); a vehicle with other constants
- * (the reference is edited or subclassed for that) runs kernels that read them at run time, 1.15x (same structure) to 1.8x
- * (arbitrary constants) slower.  mvrl_specialize compiles the step kernel once more, with hiprtc, for THIS handle's
- * constants (about a second) and switches the handle to it: same arithmetic, same arguments, mvrl_variant() gains "jit-".
- * No-op for handles that already run the literal-constant kernel.  Fails with MVRL_EHIP and the compiler log in
- * mvrl_last_error when hiprtc is unavailable; the handle then keeps its ahead-of-time kernel.
- * mvrl_jit_compile_check performs the compilation alone (no GPU, nothing loaded): build and CI check. ---- */
+ * (the reference is edited or subclassed for that) runs kernels that read them at run time, 1.13x (same structure) to 1.85x
+ * (arbitrary constants) slower.  mvrl_specialize compiles the step kernel once more for THIS handle's constants - the
+ * library carries its kernel sources; compiler: the ROCm installation's hipcc as a child process ($MVRL_HIPCC, else
+ * /opt/rocm/bin/hipcc, else hipcc on PATH; 2-3 s), falling back to in-process hiprtc; MVRL_JIT_COMPILER=hipcc|hiprtc pins
+ * it - and switches the handle to it: same arithmetic, same arguments, mvrl_variant() gains "jit-".  Structured constants
+ * then run at the default vehicle's speed, arbitrary ones 1.3x slower than it.  No-op for handles that already run the
+ * literal-constant kernel.  On failure (no compiler) returns MVRL_EHIP with the compiler's log in mvrl_last_error and the
+ * handle keeps its ahead-of-time kernel.
+ * mvrl_jit_compile_check performs the compilation alone (no GPU, nothing loaded): build and CI check; log_buf receives the
+ * two kernel names and which compiler produced them. ---- */
 int mvrl_specialize(mvrl_handle* h);
 int mvrl_jit_compile_check(const mvrl_rov6_params* params, int control_mode, size_t* code_size, char* log_buf, size_t log_cap);
 

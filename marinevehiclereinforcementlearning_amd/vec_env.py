@@ -63,9 +63,10 @@ class MarineVecEnv:
     (`dt`, `maxSteps` - 6DoF.py:446 / 3DoF.py:376; `noiseMagCoeffs`, `noiseMagActuation`, `currentVelScale`,
     `currentTurbScale`, `stopOnBoundsExceeded` - verySimpleAuv.py:77-78) plus the integrator settings that are
     this build's (`n_substeps`, `control_mode`).  `specialize=True` (6-DoF with `vehicle_params` other than the
-    reference's): compile the step kernel for those constants at construction (hiprtc, about a second; mvrl_specialize);
-    `specialize="auto"` does so only where it pays on today's runtime - arbitrary constants (the `generic` flavour: -23 % per
-    step; structured constants break even).
+    reference's): compile the step kernel for those constants at construction (the ROCm installation's hipcc as a child
+    process, 2-3 s; mvrl_specialize) - structured constants then run at the speed of the default vehicle, arbitrary ones
+    30 % faster than the run-time-constant kernel.  `specialize="auto"`: whenever the handle is a fp32
+    6-DoF RK4 handle with non-default constants.
     """
 
     metadata = {"render.modes": []}
@@ -101,7 +102,8 @@ class MarineVecEnv:
                                  integrator=integrator, **kw)
         self.dt = self.cfg.dt
         self._h = _lib.Handle(self.cfg)
-        if specialize is True or (specialize == "auto" and "/generic/" in self._h.variant and precision == "f32" and integrator == "rk4"):
+        if specialize is True or (specialize == "auto" and self.model == P.MODEL_ROV6 and "/baked/" not in self._h.variant
+                                  and precision == "f32" and integrator == "rk4"):
             self._h.specialize()
         self.flow = flow
         if use_flow:

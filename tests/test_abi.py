@@ -113,4 +113,24 @@ def test_jit_specialisation_compiles_without_a_gpu():
         rc = lib.mvrl_jit_compile_check(C.addressof(p6), mode, C.addressof(size), log, len(log))
         assert rc == 0, log.value.decode()
         names = log.value.decode().split("\n")
-        assert size.value > 10000 and len(names) == 2 and all("rov6_step_kernel" in nm and tag in nm for nm in names), names
+        assert size.value > 10000 and len(names) == 3 and all("rov6_step_kernel" in nm and tag in nm for nm in names[:2]), names
+        assert names[2] in ("compiled by hipcc", "compiled by hiprtc")
+
+
+def test_jit_specialisation_with_either_compiler(monkeypatch):
+    """The two compilers mvrl_specialize can use: the ROCm installation's hipcc as a child process (preferred: a process that
+    imports PyTorch has PyTorch's older libhiprtc / comgr loaded, whose code for this kernel spills) and in-process hiprtc."""
+    import ctypes as C
+    from marinevehiclereinforcementlearning_amd import _lib, params as P
+    lib = _lib.load()
+    p6 = P.rov6_params(m=12.0, Xuu=-19.0)
+    for compiler in ("hipcc", "hiprtc"):
+        monkeypatch.setenv("MVRL_JIT_COMPILER", compiler)
+        size, log = C.c_size_t(0), C.create_string_buffer(8192)
+        rc = lib.mvrl_jit_compile_check(C.addressof(p6), P.CTRL_FAITHFUL, C.addressof(size), log, len(log))
+        assert rc == 0 and size.value > 10000 and log.value.decode().endswith("compiled by " + compiler), log.value.decode()
+    monkeypatch.setenv("MVRL_JIT_COMPILER", "hipcc")
+    monkeypatch.setenv("MVRL_HIPCC", "/nonexistent/hipcc")
+    size, log = C.c_size_t(0), C.create_string_buffer(8192)
+    assert lib.mvrl_jit_compile_check(C.addressof(p6), P.CTRL_FAITHFUL, C.addressof(size), log, len(log)) != 0
+    assert "cannot start" in log.value.decode() or "failed" in log.value.decode()

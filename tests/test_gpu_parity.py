@@ -183,7 +183,7 @@ def test_generic_kernel_with_modified_constants(oracle_mod):
 
 
 def test_specialised_kernels_for_non_default_constants(oracle_mod):
-    """mvrl_specialize: the step kernel compiled at run time (hiprtc) with the handle's own constants as literals - arbitrary
+    """mvrl_specialize: the step kernel compiled at run time (hipcc child process) with the handle's own constants as literals - arbitrary
     constants (dense form), BlueROV2-structured ones and a retuned controller, FAITHFUL and ZOH, with and without the
     turbulence composition - against the fp64 oracle with the same constants, like the ahead-of-time flavours above; K-step
     roll-outs and lane-range launches go through the same compiled function."""
