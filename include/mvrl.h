@@ -189,8 +189,9 @@ void mvrl_destroy(mvrl_handle* h);
 
 /* Upload the scaled turbulence table (host float32 [n_t][n_y][n_x][2]).
  * Replaces the table held by ReconstructedFlow after scale() (flowGenerator.py:76-95).  The handle keeps its own copy in
- * the layout its kernels read - the two time slices an interpolation needs side by side in one 16-byte cell: twice the
- * table's size in device memory, 2.5 instead of 4.5 scattered cache lines per lookup. */
+ * the layout its kernels read - the 2 x 2 x 2 interpolation stencil of every cell in one 64-byte cache line: eight times
+ * the table's size in device memory (320 MB for 2000 snapshots of 41 x 61), one instead of 4.5 scattered cache lines per
+ * lookup. */
 int mvrl_set_flow(mvrl_handle* h, const float* table_host, const mvrl_flow_desc* desc);
 int mvrl_set_flow_f64(mvrl_handle* h, const double* table_host, const mvrl_flow_desc* desc);
 /* Same, table already resident on the handle's device in the handle's precision (read once, here: later changes to the

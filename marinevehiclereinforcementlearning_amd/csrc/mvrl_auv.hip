@@ -118,7 +118,7 @@ __device__ __forceinline__ void auv_step_core(const AuvDev& p, const FlowDev& fl
     float sn, c;
     sincos_f32(s.psi, sn, c);
     float2 cur = make_float2(0.f, 0.f);
-    if (FLOW) cur = flow_interp_uv<true>(fl, time + s.toff, s.x, s.y);                      // :291 (one-line stencil cells)
+    if (FLOW) cur = flow_interp_uv(fl, time + s.toff, s.x, s.y);                            // :291
     const float dvx = s.vx - cur.x, dvy = s.vy - cur.y;
     const float vr0 = c * dvx + sn * dvy, vr1 = -sn * dvx + c * dvy;                        // :298 (pinv(J) = J^T)
     const float Fh0 = (p.xu * s.mu[5] + p.xuu * s.mu[2] * fabsf(vr0)) * vr0;                // :303-307

@@ -164,14 +164,12 @@ __device__ __host__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 
 
 // ---- turbulence table -----------------------------------------------------------------------------
 struct FlowDev {
-    // [n_t][n_y][n_x] of (u, v at slice t; u, v at slice t + 1): the two time slices an interpolation needs sit in ONE
-    // 16-byte cell (the library builds this from the caller's plain [n_t][n_y][n_x][2] table at mvrl_set_flow: 2 x the
-    // memory).  A lookup then touches the two grid rows of one slice pair - 2.5 cache lines per lane on average instead
-    // of 4.5 - and scattered line requests, not bytes, are what the gathers cost: 9.5 us per million of them on a chip
-    // that is streaming the state planes at the same time (tools/plane_layout.hip).
-    // AuvEnv handles (HBM-bound, the gathers are a third of their step) go one further: cell (t, y, x) = the whole
-    // 2 x 2 x 2 stencil, 64 bytes = exactly one cache line per lookup, [dt][dy][dx] x (u, v): 8 x the plain table
-    // (flow_gather<true>).
+    // [n_t][n_y][n_x] cells of 64 bytes: cell (t, y, x) holds the whole 2 x 2 x 2 interpolation stencil,
+    // [dt][dy][dx] x (u, v) - exactly ONE cache line per lookup.  The library builds this from the caller's plain
+    // [n_t][n_y][n_x][2] table at mvrl_set_flow (8 x the memory: 320 MB for the 2000-snapshot table).  In the plain
+    // table a lookup touches four grid rows = 4.5 lines per lane, and scattered line requests, not bytes, are what the
+    // gathers cost: 9.5 us per million of them on a chip that is streaming the state planes at the same time
+    // (tools/plane_layout.hip) - a third of an AuvEnv step.
     const float4* table;
     int n_t, n_y, n_x;
     float inv_dt, inv_dx, inv_dy;
@@ -181,12 +179,11 @@ struct FlowDev {
 // ReconstructedFlow.interp restricted to (u, v) (tag/flowGenerator.py:97-136): cell index clamped, weights NOT
 // clamped (linear extrapolation outside the table), origin ignored - all as the reference.
 // Split in two so that a kernel can issue the gathers early and consume them late (the loads are a dependent HBM /
-// Infinity-Cache round trip): flow_gather = index arithmetic + the 8 loads, flow_combine = the interpolation.
+// Infinity-Cache round trip): flow_gather = index arithmetic + the loads, flow_combine = the interpolation.
 struct FlowTap {
     float2 c000, c001, c010, c011, c100, c101, c110, c111;
     float ft, fx, fy;
 };
-template <bool FULL_CELL = false>
 __device__ __forceinline__ FlowTap flow_gather(const FlowDev& f, float time, float x, float y) {
     FlowTap g;
     float tt = time * f.inv_dt, xx = x * f.inv_dx, yy = y * f.inv_dy;
@@ -194,23 +191,13 @@ __device__ __forceinline__ FlowTap flow_gather(const FlowDev& f, float time, flo
     int ii = min(f.n_x - 2, max(0, (int)floorf(xx)));
     int jj = min(f.n_y - 2, max(0, (int)floorf(yy)));
     g.ft = tt - (float)kk; g.fx = xx - (float)ii; g.fy = yy - (float)jj;
-    if (FULL_CELL) {   // one line: (x0, x1) of row y0 at t0 | row y1 at t0 | row y0 at t1 | row y1 at t1
-        const float4* q = f.table + (((size_t)kk * f.n_y + jj) * f.n_x + ii) * 4;
-        const float4 a = q[0], b = q[1], c = q[2], d = q[3];
-        g.c000 = make_float2(a.x, a.y); g.c001 = make_float2(a.z, a.w);
-        g.c010 = make_float2(b.x, b.y); g.c011 = make_float2(b.z, b.w);
-        g.c100 = make_float2(c.x, c.y); g.c101 = make_float2(c.z, c.w);
-        g.c110 = make_float2(d.x, d.y); g.c111 = make_float2(d.z, d.w);
-        return g;
-    }
-    const float4* p = f.table + ((size_t)kk * f.n_y + jj) * f.n_x + ii;
-    // 4 corner gathers of 16 B, each holding the corner's values at slices kk and kk + 1 (kk <= n_t - 2); the x-neighbours
-    // are adjacent in memory
-    const float4 a = p[0], b = p[1], c = p[f.n_x], d = p[f.n_x + 1];
-    g.c000 = make_float2(a.x, a.y); g.c100 = make_float2(a.z, a.w);
-    g.c001 = make_float2(b.x, b.y); g.c101 = make_float2(b.z, b.w);
-    g.c010 = make_float2(c.x, c.y); g.c110 = make_float2(c.z, c.w);
-    g.c011 = make_float2(d.x, d.y); g.c111 = make_float2(d.z, d.w);
+    // one line: (x0, x1) of row y0 at t0 | row y1 at t0 | row y0 at t1 | row y1 at t1
+    const float4* q = f.table + (((size_t)kk * f.n_y + jj) * f.n_x + ii) * 4;
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    g.c000 = make_float2(a.x, a.y); g.c001 = make_float2(a.z, a.w);
+    g.c010 = make_float2(b.x, b.y); g.c011 = make_float2(b.z, b.w);
+    g.c100 = make_float2(c.x, c.y); g.c101 = make_float2(c.z, c.w);
+    g.c110 = make_float2(d.x, d.y); g.c111 = make_float2(d.z, d.w);
     return g;
 }
 __device__ __forceinline__ float2 flow_combine(const FlowTap& g) {
@@ -221,9 +208,8 @@ __device__ __forceinline__ float2 flow_combine(const FlowTap& g) {
     float v1 = wy0 * (g.c100.y * wx0 + g.c101.y * fx) + fy * (g.c110.y * wx0 + g.c111.y * fx);
     return make_float2(u0 * wt0 + u1 * ft, v0 * wt0 + v1 * ft);
 }
-template <bool FULL_CELL = false>
 __device__ __forceinline__ float2 flow_interp_uv(const FlowDev& f, float time, float x, float y) {
-    return flow_combine(flow_gather<FULL_CELL>(f, time, x, y));
+    return flow_combine(flow_gather(f, time, x, y));
 }
 
 // ---- device mirrors of the model constants (fp32) -------------------------------------------------

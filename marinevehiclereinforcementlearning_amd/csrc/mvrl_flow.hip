@@ -100,28 +100,18 @@ __global__ __launch_bounds__(64) void delay_kernel(unsigned long long ticks) {
     }
 }
 
-// The step kernels' turbulence table (FlowDev::table): cell (t, y, x) = (u, v)(t) | (u, v)(min(t + 1, n_t - 1)), built from the
-// caller's plain [n_t][n_y][n_x][2] table.  T = float or double.
-// FULL: cell = the whole 2 x 2 x 2 stencil, [dt][dy][dx] x (u, v) (neighbours beyond the last row / column / slice repeat the
-// last one; lookups never read those: indices are clamped to n - 2).
-template <class T, bool FULL>
-__global__ __launch_bounds__(MVRL_BLOCK) void flow_pair_kernel(const T* __restrict__ src, T* __restrict__ dst, int n_t, int n_y, int n_x) {
+// The step kernels' turbulence table (FlowDev::table): cell (t, y, x) = the whole 2 x 2 x 2 stencil, [dt][dy][dx] x (u, v),
+// built from the caller's plain [n_t][n_y][n_x][2] table (neighbours beyond the last row / column / slice repeat the last
+// one; lookups never read those: indices are clamped to n - 2).  T = float or double.
+template <class T>
+__global__ __launch_bounds__(MVRL_BLOCK) void flow_cell_kernel(const T* __restrict__ src, T* __restrict__ dst, int n_t, int n_y, int n_x) {
     const int64_t cells = (int64_t)n_y * n_x;
     const int64_t c = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
     const int t = blockIdx.y;
     if (c >= cells) return;
-    const int t1 = t + 1 < n_t ? t + 1 : t;
-    if (!FULL) {
-        const T* a = src + ((int64_t)t * cells + c) * 2;
-        const T* b = src + ((int64_t)t1 * cells + c) * 2;
-        T* d = dst + ((int64_t)t * cells + c) * 4;
-        d[0] = a[0]; d[1] = a[1]; d[2] = b[0]; d[3] = b[1];
-        return;
-    }
     const int y = (int)(c / n_x), x = (int)(c % n_x);
-    const int y1 = y + 1 < n_y ? y + 1 : y, x1 = x + 1 < n_x ? x + 1 : x;
+    const int ts[2] = {t, t + 1 < n_t ? t + 1 : t}, ys[2] = {y, y + 1 < n_y ? y + 1 : y}, xs[2] = {x, x + 1 < n_x ? x + 1 : x};
     T* d = dst + ((int64_t)t * cells + c) * 16;
-    const int ts[2] = {t, t1}, ys[2] = {y, y1}, xs[2] = {x, x1};
 #pragma unroll
     for (int it = 0; it < 2; it++)
 #pragma unroll
@@ -134,13 +124,11 @@ __global__ __launch_bounds__(MVRL_BLOCK) void flow_pair_kernel(const T* __restri
             }
 }
 
-hipError_t launch_flow_pair(const void* src, void* dst, int n_t, int n_y, int n_x, bool full, bool f64, hipStream_t stream) {
+hipError_t launch_flow_cells(const void* src, void* dst, int n_t, int n_y, int n_x, bool f64, hipStream_t stream) {
     const int64_t cells = (int64_t)n_y * n_x;
     dim3 grid((unsigned)((cells + MVRL_BLOCK - 1) / MVRL_BLOCK), (unsigned)n_t), block(MVRL_BLOCK);
-    if (f64 && full) hipLaunchKernelGGL((flow_pair_kernel<double, true>), grid, block, 0, stream, (const double*)src, (double*)dst, n_t, n_y, n_x);
-    else if (f64) hipLaunchKernelGGL((flow_pair_kernel<double, false>), grid, block, 0, stream, (const double*)src, (double*)dst, n_t, n_y, n_x);
-    else if (full) hipLaunchKernelGGL((flow_pair_kernel<float, true>), grid, block, 0, stream, (const float*)src, (float*)dst, n_t, n_y, n_x);
-    else hipLaunchKernelGGL((flow_pair_kernel<float, false>), grid, block, 0, stream, (const float*)src, (float*)dst, n_t, n_y, n_x);
+    if (f64) hipLaunchKernelGGL(flow_cell_kernel<double>, grid, block, 0, stream, (const double*)src, (double*)dst, n_t, n_y, n_x);
+    else hipLaunchKernelGGL(flow_cell_kernel<float>, grid, block, 0, stream, (const float*)src, (float*)dst, n_t, n_y, n_x);
     return hipGetLastError();
 }
 

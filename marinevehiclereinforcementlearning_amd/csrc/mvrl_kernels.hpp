@@ -41,7 +41,7 @@ hipError_t launch_los_policy(const float* obs, int obs_dim, float* actions, int6
 hipError_t launch_replay_add_sym(const float* obs, const float* next_obs, const float* act, const float* rew, const uint8_t* done,
                                  const uint8_t* timeout, int64_t n_envs, float* b_obs, float* b_next, float* b_act, float* b_rew,
                                  uint8_t* b_done, uint8_t* b_timeout, int64_t buffer_size, int64_t pos, int n_tr, hipStream_t stream);
-hipError_t launch_flow_pair(const void* src, void* dst, int n_t, int n_y, int n_x, bool full, bool f64, hipStream_t stream);
+hipError_t launch_flow_cells(const void* src, void* dst, int n_t, int n_y, int n_x, bool f64, hipStream_t stream);
 hipError_t launch_delay(int microseconds, hipStream_t stream);
 hipError_t launch_fill_uniform(float* dst, int64_t n, uint64_t seed, uint64_t counter, float lo, float hi,
                                hipStream_t stream);
