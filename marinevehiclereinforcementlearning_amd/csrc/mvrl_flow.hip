@@ -107,26 +107,28 @@ template <class T>
 __global__ __launch_bounds__(MVRL_BLOCK) void flow_cell_kernel(const T* __restrict__ src, T* __restrict__ dst, int n_t, int n_y, int n_x) {
     const int64_t cells = (int64_t)n_y * n_x;
     const int64_t c = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
-    const int t = blockIdx.y;
     if (c >= cells) return;
     const int y = (int)(c / n_x), x = (int)(c % n_x);
-    const int ts[2] = {t, t + 1 < n_t ? t + 1 : t}, ys[2] = {y, y + 1 < n_y ? y + 1 : y}, xs[2] = {x, x + 1 < n_x ? x + 1 : x};
-    T* d = dst + ((int64_t)t * cells + c) * 16;
+    const int ys[2] = {y, y + 1 < n_y ? y + 1 : y}, xs[2] = {x, x + 1 < n_x ? x + 1 : x};
+    for (int t = blockIdx.y; t < n_t; t += gridDim.y) {   // grid.y is capped at 65 535
+        const int ts[2] = {t, t + 1 < n_t ? t + 1 : t};
+        T* d = dst + ((int64_t)t * cells + c) * 16;
 #pragma unroll
-    for (int it = 0; it < 2; it++)
+        for (int it = 0; it < 2; it++)
 #pragma unroll
-        for (int iy = 0; iy < 2; iy++)
+            for (int iy = 0; iy < 2; iy++)
 #pragma unroll
-            for (int ix = 0; ix < 2; ix++) {
-                const T* a = src + (((int64_t)ts[it] * n_y + ys[iy]) * n_x + xs[ix]) * 2;
-                d[((it * 2 + iy) * 2 + ix) * 2 + 0] = a[0];
-                d[((it * 2 + iy) * 2 + ix) * 2 + 1] = a[1];
-            }
+                for (int ix = 0; ix < 2; ix++) {
+                    const T* a = src + (((int64_t)ts[it] * n_y + ys[iy]) * n_x + xs[ix]) * 2;
+                    d[((it * 2 + iy) * 2 + ix) * 2 + 0] = a[0];
+                    d[((it * 2 + iy) * 2 + ix) * 2 + 1] = a[1];
+                }
+    }
 }
 
 hipError_t launch_flow_cells(const void* src, void* dst, int n_t, int n_y, int n_x, bool f64, hipStream_t stream) {
     const int64_t cells = (int64_t)n_y * n_x;
-    dim3 grid((unsigned)((cells + MVRL_BLOCK - 1) / MVRL_BLOCK), (unsigned)n_t), block(MVRL_BLOCK);
+    dim3 grid((unsigned)((cells + MVRL_BLOCK - 1) / MVRL_BLOCK), (unsigned)(n_t < 65535 ? n_t : 65535)), block(MVRL_BLOCK);
     if (f64) hipLaunchKernelGGL(flow_cell_kernel<double>, grid, block, 0, stream, (const double*)src, (double*)dst, n_t, n_y, n_x);
     else hipLaunchKernelGGL(flow_cell_kernel<float>, grid, block, 0, stream, (const float*)src, (float*)dst, n_t, n_y, n_x);
     return hipGetLastError();

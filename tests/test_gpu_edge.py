@@ -102,3 +102,50 @@ def test_angle_error_ties_fp32(oracle_mod):
     zero = d == 0
     assert zero.sum() >= 1 and np.all(out[zero] == 0)
     h.close()
+
+
+def test_turbulence_lookup_at_and_beyond_the_table_edges(oracle_mod):
+    """The step kernels read the turbulence table through re-packed stencil cells (mvrl_set_flow: one 64-byte cell per
+    (t, y, x) holding the 2 x 2 x 2 stencil).  Lookups with the index clamped at either end and the weight NOT clamped
+    (flowGenerator.py:108-117: linear extrapolation) must read the same eight values as the plain table: AuvEnv envs placed
+    below, inside, on the last cell of and far beyond the grid, at time offsets before the first, at the last and beyond the
+    last snapshot; stop_on_bounds off so that they keep stepping.  fp32 and fp64 handles, host and device table entry points."""
+    import torch
+    rng = np.random.default_rng(17)
+    n_t, n_y, n_x, dt, dx, dy = 12, 9, 11, 0.05, 0.25, 0.3
+    uv = rng.normal(0, 0.3, (n_t, n_y, n_x, 2))
+    xs = np.array([-0.6, -1e-3, 0.0, 0.1, (n_x - 2) * dx, (n_x - 2) * dx + 0.2, (n_x - 1) * dx, (n_x - 1) * dx + 0.7])
+    ys = np.array([-0.5, 0.0, 0.7, (n_y - 2) * dy + 0.1, (n_y - 1) * dy, (n_y - 1) * dy + 0.8])
+    toffs = np.array([0.0, 0.26, (n_t - 2) * dt - 0.02, (n_t - 1) * dt - 0.02, (n_t - 1) * dt + 0.2])
+    grid = np.array([(x, y, t) for x in xs for y in ys for t in toffs])
+    n = len(grid)
+    init = np.zeros((n, 16))
+    init[:, 0], init[:, 1], init[:, 4] = grid[:, 0], grid[:, 1], grid[:, 2]
+    init[:, 2] = rng.random(n) * 2 * np.pi
+    init[:, 3] = rng.random(n) * 2 * np.pi
+    init[:, 5:] = 1.0
+    auv = P.auv_params(stopOnBoundsExceeded=False)
+    acts = rng.uniform(-1, 1, (3, n, 3))
+    # fp32: extrapolation weights of 3 - 5 in each of the three directions multiply the rounding of the interpolation
+    for precision, tol in (("f64", 1e-10), ("f32", 2e-4)):
+        dtype = np.float64 if precision == "f64" else np.float32
+        env = oracle_mod.OracleAuvEnv(n, "f64", dt=0.02, max_steps=10 ** 6, flow=oracle_mod.FlowTable(uv, dt, dx, dy), auv=auv)
+        env.reset(init.astype(dtype).astype(np.float64))
+        ref = [tuple(np.copy(a) for a in env.step(acts[k].astype(dtype).astype(np.float64))) + (env.pose.copy(), env.aux.copy()) for k in range(3)]
+        for entry in ("host", "device"):
+            h = _lib.Handle(P.make_config("auv", n, dt=0.02, auto_reset=False, max_steps=10 ** 6, use_flow=True, auv=auv, precision=precision))
+            if entry == "host":
+                h.set_flow(uv.astype(dtype), dt, dx, dy)
+            else:
+                tbl = torch.as_tensor(uv.astype(dtype), device="cuda").contiguous()
+                h.set_flow_dev(tbl.data_ptr(), n_t, n_y, n_x, dt, dx, dy)
+                del tbl                                        # the handle keeps its own re-packed copy
+                torch.cuda.empty_cache()
+            h.reset(init=init.astype(dtype))
+            for k in range(3):
+                o, r, d = h.step(acts[k].astype(dtype))
+                o_ref, r_ref, d_ref, pose_ref, aux_ref = ref[k]
+                # velCurrent (u, v) is among the step's side outputs: the looked-up value itself
+                assert max_scaled_err(h.get_state()[:6].T, pose_ref) < tol, (precision, entry, k)
+                assert max_scaled_err(o, o_ref) < max(tol, 1e-9) and max_scaled_err(r, r_ref) < max(tol * 3, 1e-9), (precision, entry, k)
+            h.close()
