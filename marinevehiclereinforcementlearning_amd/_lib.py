@@ -302,7 +302,7 @@ class Handle:
         return out
 
     def specialize(self):
-        """Compile the 6-DoF step kernel for this handle's constants (hiprtc) and switch to it (mvrl_specialize)."""
+        """Compile the 6-DoF step kernel for this handle's constants (hipcc child process, hiprtc fallback) and switch to it (mvrl_specialize)."""
         check(self.lib.mvrl_specialize(self.h), self.h)
         return self.variant
 

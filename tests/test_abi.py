@@ -101,7 +101,7 @@ def test_baked_table_matches_params():
 
 
 def test_jit_specialisation_compiles_without_a_gpu():
-    """mvrl_specialize's compilation step (hiprtc, gfx950) for the default, a BlueROV2-structured and an arbitrary set of
+    """mvrl_specialize's compilation step (hipcc or hiprtc, gfx950) for the default, a BlueROV2-structured and an arbitrary set of
     constants, both controller placements: the library carries its own kernel sources and they build at run time."""
     import ctypes as C
     from marinevehiclereinforcementlearning_amd import _lib, params as P
