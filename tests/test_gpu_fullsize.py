@@ -48,12 +48,19 @@ def test_kernel_flavours_agree_at_full_size():
     ps.dlin[0] = ps.dlin[0] * (1 + 1.5e-7)   # one ulp in a vehicle constant (linear surge damping) -> structured run-time constants
     hs = _lib.Handle(P.make_config("rov6", n, auto_reset=False, max_steps=10 ** 9, use_flow=False, rov6=ps))
     assert "baked" in hb.variant and "ctrl" in hc.variant and "sym" in hs.variant, (hb.variant, hc.variant, hs.variant)
-    for h in (hb, hc, hs):
+    # ... and the same one-ulp vehicle compiled at run time with its constants as literals (mvrl_specialize)
+    hj = _lib.Handle(P.make_config("rov6", n, auto_reset=False, max_steps=10 ** 9, use_flow=False, rov6=ps))
+    assert "jit-sym" in hj.specialize()
+    for h in (hb, hc, hs, hj):
         h.reset(init=init)
     for s in range(5):
-        for h in (hb, hc, hs):
+        for h in (hb, hc, hs, hj):
             h.step(acts[s])
     a = hb.get_state()[:12]
+    hj_state = hj.get_state()[:12]
+    hj.close()
+    # literal constants either way, one constant apart by one ulp: the specialised kernel tracks the baked one closely
+    assert np.median(np.abs(hj_state - a).max(axis=0)) < 2e-6
     for h in (hc, hs):
         b = h.get_state()[:12]
         d = np.abs(a - b)
