@@ -2,13 +2,13 @@
 """Distribution of the fp32-vs-fp64 trajectory error of the 6-DoF step kernel (GPU box): per-env maximum scaled error over a
 seeded random-action run, as quantiles, plus the drift / jump split of tests/parity_util.OutlierAudit.  Used to compare
 kernel revisions (MVRL_LIB selects the library): a change that only re-orders roundings must leave the quantiles where
-they were.   python tools/err_quantiles.py [n] [steps] [n_sub] [mode] [dof]"""
+they were.   python tests/audit/err_quantiles.py [n] [steps] [n_sub] [mode] [dof]"""
 import os
 import sys
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from marinevehiclereinforcementlearning_amd import _lib, params as P  # noqa: E402
 from oracle import oracle as oracle_mod  # noqa: E402   (a measuring tool, like the tests: not a product path)

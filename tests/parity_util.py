@@ -11,7 +11,7 @@ one of them at some step <= s.  Envs beyond tolerance WITHOUT such an approach f
 """
 import numpy as np
 
-# fp32 bounds, in the units of oracle.OracleRovEnv.margins.  Calibrated on 6 x 16384 envs x 60 steps (tools/margin_probe.py,
+# fp32 bounds, in the units of oracle.OracleRovEnv.margins.  Calibrated on 6 x 16384 envs x 60 steps (tests/audit/margin_probe.py,
 # gpurun_out/r2_margins*.log): the largest distance seen on an env that jumped off x ~3.
 F32_BOUNDS = np.array([
     3e-5,    # |e - eOld| / (h x sum_j |J_ij nu_j|) at a zero-dt PID call: how completely the terms of a pose rate cancel; fp32
@@ -108,7 +108,7 @@ class OutlierAudit:
     def assert_explained(self, max_share=None, max_smooth_share=0.002, resolver=None):
         """resolver(lanes, jump_steps) -> bool[len(lanes)] (see `ensemble_sensitive`): second line of defence for envs whose
         jump the distance bounds do not cover - the stated bounds are calibrated on ~1e6 env-steps, and about 1 jump in 100
-        happens a few bounds away (measured on 2.6e7 env-steps, tools/err_quantiles.py).  Such an env passes only if the fp64
+        happens a few bounds away (measured on 2.6e7 env-steps, tests/audit/err_quantiles.py).  Such an env passes only if the fp64
         reference itself, perturbed at fp32-rounding level, leaves its own unperturbed trajectory there."""
         un = np.nonzero(self.unexplained())[0]
         if len(un) and resolver is not None:
@@ -124,7 +124,7 @@ class OutlierAudit:
 
 # Relative size of the per-sub-step state perturbation of `ensemble_sensitive`.  fp32 storage of the state alone is 6e-8 (half an
 # ulp); the kernels round ~6000 operations per env step on top, and the deviation they accumulate is smooth and small: median
-# 2.0e-6, 99.99 % below 5e-6 after 25 steps (tools/err_quantiles.py, 1 048 576 envs).  The ensemble uses the level at which
+# 2.0e-6, 99.99 % below 5e-6 after 25 steps (tests/audit/err_quantiles.py, 1 048 576 envs).  The ensemble uses the level at which
 # its own median deviation matches that accepted typical deviation - not more.
 ENSEMBLE_NOISE = 1e-7
 

@@ -130,7 +130,7 @@ def test_random_batch_vs_fp64_oracle(oracle_mod, dof, mode, n_sub):
     # measured (gpurun_out/r2_margins2.log): 7, 2, 1, 1, 4, 29 of 4096 envs for the six parametrisations
     budget = {(6, P.CTRL_FAITHFUL, 4): 0.004, (6, P.CTRL_FAITHFUL, 8): 0.016, (6, P.CTRL_FAITHFUL, 2): 0.002}.get((dof, mode, n_sub), 0.001)
     # envs that drift past 1e-5 without ever jumping: 0.003 % (FAITHFUL, n_sub 4), 0.03 % (n_sub 8), 0.05 % (ZOH) of 65 536 envs
-    # (tools/err_quantiles.py, gpurun_out/r2_errq18.log) - bounded at twice the measured share
+    # (tests/audit/err_quantiles.py, gpurun_out/r2_errq18.log) - bounded at twice the measured share
     audit.assert_explained(max_share=budget, max_smooth_share=0.001 if mode == P.CTRL_ZOH or n_sub == 8 else 0.0005,
                            resolver=make_resolver(oracle_mod, dof, init, actions, dict(n_substeps=n_sub, control_mode=mode)))
     assert med < 2e-6, med

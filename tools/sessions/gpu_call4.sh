@@ -4,7 +4,7 @@
 OUT=gpurun_out
 mkdir -p $OUT
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-timeout -k 10 600 python tools/margin_probe.py > $OUT/r2_margins.log 2>&1; rc=$?; echo "margins rc=$rc"; tail -3 $OUT/r2_margins.log
+timeout -k 10 600 python tests/audit/margin_probe.py > $OUT/r2_margins.log 2>&1; rc=$?; echo "margins rc=$rc"; tail -3 $OUT/r2_margins.log
 if [ $rc -ge 124 ]; then exit $rc; fi
 timeout -k 10 600 python -m pytest tests/test_gpu_edge.py tests/test_gpu_chains.py "tests/test_gpu_api.py::test_rollout_equals_k_steps" -m gpu -q > $OUT/r2_t4.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -6 $OUT/r2_t4.log
 if [ $rc -ge 124 ]; then exit $rc; fi

@@ -2,8 +2,8 @@
 OUT=gpurun_out
 mkdir -p $OUT
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-timeout -k 10 600 python tools/margin_probe.py > $OUT/r2_margins4.log 2>&1; rc=$?; echo "margins rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
-N=16384 STEPS=60 timeout -k 10 900 python tools/margin_probe.py > $OUT/r2_margins5.log 2>&1; rc=$?; echo "margins5 rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
+timeout -k 10 600 python tests/audit/margin_probe.py > $OUT/r2_margins4.log 2>&1; rc=$?; echo "margins rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
+N=16384 STEPS=60 timeout -k 10 900 python tests/audit/margin_probe.py > $OUT/r2_margins5.log 2>&1; rc=$?; echo "margins5 rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
 timeout -k 10 1100 python -m pytest tests -m gpu -q -s > $OUT/r2_t7.log 2>&1
 rc=$?; echo "pytest rc=$rc"; tail -8 $OUT/r2_t7.log | cut -c1-300
 if [ $rc -ge 124 ]; then exit $rc; fi
