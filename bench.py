@@ -178,7 +178,7 @@ def main():
               "generic": lambda: P_.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3, m=12.0)}[args.flavour]()
     env = MarineVecEnv(wl["model"], n, seed=args.seed, n_substeps=args.n_substeps, control_mode=args.control_mode,
                        flow=flow, device=local_rank, env_offset=rank * n, infos="lean", precision=args.precision,
-                       vehicle_params=vp, specialize=args.specialize and (vp is not None or bool(os.environ.get("MVRL_JIT_FORCE"))))
+                       vehicle_params=vp, specialize=bool(args.specialize and (vp is not None or os.environ.get("MVRL_JIT_FORCE"))))
     act_dim, obs_dim = env.action_space.shape[0], env.observation_space.shape[0]
     h = env.handle
     stream = torch.cuda.current_stream().cuda_stream

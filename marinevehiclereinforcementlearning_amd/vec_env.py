@@ -65,8 +65,9 @@ class MarineVecEnv:
     this build's (`n_substeps`, `control_mode`).  `specialize=True` (6-DoF with `vehicle_params` other than the
     reference's): compile the step kernel for those constants at construction (the ROCm installation's hipcc as a child
     process, 2-3 s; mvrl_specialize) - structured constants then run at the speed of the default vehicle, arbitrary ones
-    30 % faster than the run-time-constant kernel.  `specialize="auto"`: whenever the handle is a fp32
-    6-DoF RK4 handle with non-default constants.
+    30 % faster than the run-time-constant kernel.  `specialize="auto"` (default): whenever the handle
+    is a fp32 6-DoF RK4 handle with non-default constants, keeping the ahead-of-time kernel (with a warning) if no compiler is
+    available; `True`: insist (raise on failure); `False`: never.
     """
 
     metadata = {"render.modes": []}
@@ -74,7 +75,7 @@ class MarineVecEnv:
     def __init__(self, model, num_envs, *, seed=0, dt=None, maxSteps=250, n_substeps=4, control_mode="faithful",
                  fixed_setpoint=False, flow=None, currentVelScale=1.0, currentTurbScale=2.0, noiseMagCoeffs=0.0,
                  noiseMagActuation=0.0, stopOnBoundsExceeded=True, device=0, env_offset=0, infos="dict",
-                 vehicle_params=None, precision="f32", integrator="rk4", report_truncation=False, specialize=False):
+                 vehicle_params=None, precision="f32", integrator="rk4", report_truncation=False, specialize="auto"):
         cyl = model == "auv_cyl"          # AuvEnvCyl: AuvEnv with way-points (tag/verySimpleAuv_cyl.py)
         if cyl:
             model = "auv"
@@ -102,9 +103,15 @@ class MarineVecEnv:
                                  integrator=integrator, **kw)
         self.dt = self.cfg.dt
         self._h = _lib.Handle(self.cfg)
-        if specialize is True or (specialize == "auto" and self.model == P.MODEL_ROV6 and "/baked/" not in self._h.variant
-                                  and precision == "f32" and integrator == "rk4"):
+        if specialize is True:
             self._h.specialize()
+        elif (specialize == "auto" and self.model == P.MODEL_ROV6 and "/baked/" not in self._h.variant and precision == "f32"
+              and integrator == "rk4"):
+            try:
+                self._h.specialize()
+            except _lib.MvrlError as e:   # no compiler on this machine: the ahead-of-time kernel keeps running
+                import warnings
+                warnings.warn(f"mvrl_specialize failed, keeping the run-time-constant kernel ({self._h.variant}): {e}")
         self.flow = flow
         if use_flow:
             if self.model == P.MODEL_AUV:

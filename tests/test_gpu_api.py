@@ -569,6 +569,8 @@ def test_rollout_equals_k_steps(kind, kw):
         extra["vehicle_params"] = P.rov6_params(m=12.0, Xuu=-19.0)
     if flavour == "generic":
         extra["vehicle_params"] = P.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3)
+    if flavour:
+        extra["specialize"] = False    # the ahead-of-time run-time-constant kernels are what this case is about
     kw.setdefault("maxSteps", 7)                                                       # 24 steps cross three resets
     mk = lambda: MarineVecEnv(kind, n, seed=3, flow=flow, **kw, **extra)
     a, b = mk(), mk()

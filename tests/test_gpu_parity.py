@@ -236,6 +236,13 @@ def test_specialised_kernel_through_vec_env_with_turbulence_chains_and_rollouts(
         return MarineVecEnv("rov6", n, seed=4, maxSteps=5, flow=f, infos="lean", vehicle_params=p6, specialize=True)
     ea, eb, ec = mk(), mk(), mk()
     assert ea.variant == "rov6/jit-generic/faithful+flow"
+    # specialize="auto" is the default for non-default constants; False keeps the ahead-of-time kernel
+    auto = MarineVecEnv("rov6", 64, vehicle_params=p6)
+    aot = MarineVecEnv("rov6", 64, vehicle_params=p6, specialize=False)
+    base = MarineVecEnv("rov6", 64)
+    assert auto.variant == "rov6/jit-generic/faithful" and aot.variant == "rov6/generic/faithful" and base.variant == "rov6/baked/faithful"
+    for e in (auto, aot, base):
+        e.close()
     acts = torch.rand((steps, n, 6), device="cuda") * 2 - 1
     for e in (ea, eb, ec):
         e.reset_tensors()
