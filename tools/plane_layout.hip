@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64) void auv_like(float* __restrict__ st, const flo
     }
 }
 
+static int g_lds_bytes = 0;   // dynamic LDS per one-wave block: 160 KB / g_lds_bytes blocks fit a CU (occupancy limiter)
 template <int GATHER, int ROWS, int WORK>
 void run_auv(const char* tag, unsigned n, int iters) {
     float *d, *obs;
@@ -97,10 +98,10 @@ void run_auv(const char* tag, unsigned n, int iters) {
     hipMemset(table, 0, tbytes);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 20; w++) auv_like<GATHER, ROWS, WORK><<<(n + 63) / 64, 64>>>(d, table, obs, n, w);
+    for (int w = 0; w < 20; w++) auv_like<GATHER, ROWS, WORK><<<(n + 63) / 64, 64, g_lds_bytes>>>(d, table, obs, n, w);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int it = 0; it < iters; it++) auv_like<GATHER, ROWS, WORK><<<(n + 63) / 64, 64>>>(d, table, obs, n, it);
+    for (int it = 0; it < iters; it++) auv_like<GATHER, ROWS, WORK><<<(n + 63) / 64, 64, g_lds_bytes>>>(d, table, obs, n, it);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -156,5 +157,13 @@ int main() {
     run_auv<1, 1, 0>("auv + gathers + obs rows", n, 300);
     run_auv<1, 1, 200>("auv + gathers + obs rows + 200 dependent fma", n, 300);
     run_auv<1, 1, 800>("auv + gathers + obs rows + 800 dependent fma", n, 300);
+    // occupancy: the real AuvEnv step kernel holds 123 VGPRs = 4 waves per SIMD; these kernels need ~70 (7 waves)
+    for (int waves_per_simd : {8, 6, 5, 4, 3, 2}) {
+        g_lds_bytes = 160 * 1024 / (4 * waves_per_simd);
+        char tag[96];
+        snprintf(tag, sizeof(tag), "auv + 64-B cell + obs rows, 200 fma, %d waves/SIMD", waves_per_simd);
+        run_auv<6, 1, 200>(tag, n, 300);
+    }
+    g_lds_bytes = 0;
     return 0;
 }
