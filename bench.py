@@ -20,7 +20,9 @@ Inputs are resident in HBM before the timed region: a ring of pre-generated unif
 (counter-based RNG, seed 12345), random initial paths/attitudes, auto-reset every 250 steps, dt = 0.2 s,
 n_substeps = 4, control mode FAITHFUL.  Rank 0 prints ONE JSON line.
 
-For N > 1 the driver starts this file under torch.distributed.run (one rank per GPU).
+For N > 1 the driver starts this file under torch.distributed.run (one rank per GPU); started plainly (`python bench.py
+--gpus N`, no WORLD_SIZE in the environment) it launches its N ranks itself as child processes before anything touches
+the GPU (`self_launch`).
 """
 import argparse
 import json
@@ -97,6 +99,55 @@ def cpu_baseline(wl, flow_np, seed):
             "sample": f"{n} envs x {steps} steps of the same workload, fp64 C oracle with OpenMP over envs ({el:.1f} s)"}
 
 
+def self_launch(n_ranks, argv=None):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as CHILD processes (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them), relay rank 0's stdout - the ONE JSON
+    line - and return the worst exit code (the gather watchdog's exit 3 survives).  Runs before torch is imported: the
+    launcher never initialises the GPU.  A rank that dies takes the others with it after a grace period, so a broken
+    rendezvous cannot hang the job."""
+    import signal
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = str(s_.getsockname()[1])
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, MVRL_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+        # rank 0 owns the launcher's stdout (the JSON line); the other ranks' stdout goes to stderr so nothing else can
+        # end up on the result stream
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=True))
+
+    def code(p):
+        return None if p.returncode is None else (p.returncode if p.returncode >= 0 else 128 - p.returncode)
+
+    grace, first_bad = 30.0, None
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = [p for p in procs if p.returncode not in (None, 0)]
+            if bad and first_bad is None:
+                first_bad = time.monotonic()
+            if first_bad is not None and time.monotonic() - first_bad > grace:
+                for p in procs:
+                    if p.poll() is None:          # exactly the process groups started above
+                        os.killpg(p.pid, signal.SIGKILL)
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for p in procs:
+            if p.poll() is None:
+                os.killpg(p.pid, signal.SIGKILL)
+        raise
+    codes = [code(p) for p in procs]
+    # the watchdog's 3 (gather stalled) outranks the SIGKILLs this launcher handed out afterwards
+    return 3 if 3 in codes else max(codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +183,11 @@ def main():
     ap.add_argument("--seed", type=int, default=12345)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher - it has not imported torch and never touches
+        # the GPU - and the N ranks run as its children (no re-exec of a process that has initialised the GPU)
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     from marinevehiclereinforcementlearning_amd import build, distributed as D
@@ -140,8 +196,9 @@ def main():
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world_env != args.gpus:
-        sys.exit(f"bench.py --gpus {args.gpus} must be launched as: python -m torch.distributed.run --nnodes=1 "
-                 f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+        sys.exit(f"bench.py --gpus {args.gpus} found WORLD_SIZE={world_env} in the environment: start it plainly (it launches its "
+                 f"own ranks) or as python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr "
+                 f"127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
     # Rehearsal knobs for a 1-GPU box (never used by the driver): MVRL_BENCH_BACKEND=gloo lets two ranks share one
@@ -346,10 +403,9 @@ def main():
             psteps = float(pd_steps.item())
         return dict(elapsed=float(t.item()), kern_ms=kern_ms, launches=launches, pd_steps=psteps)
 
-    # Launch plans for the per-step path: "chains" (C lane ranges on C streams) and "single" (one launch per step).  Chains
-    # win once a region is long enough for their pipeline to matter (K in the hundreds: -8 %); in a 2-ms region the half-step
-    # phase offset they start with costs what they gain.  With --launch auto both plans are timed, ALTERNATING repeat by
-    # repeat so that they see the same power-controller state, and the faster median is the headline; both are in the line.
+    # Launch plans for the per-step path: "chains" (C lane ranges on C streams) and "single" (one launch per step).  With
+    # --launch auto both plans are timed, ALTERNATING repeat by repeat so that they see the same power-controller state;
+    # the headline is the plan the rule below names (`launch_plan` in the line), both are reported.
     plans = ["default"]
     if stepper is not None:
         plans = {"auto": ["chains", "single"], "chains": ["chains"], "single": ["single"]}[args.launch]
@@ -362,7 +418,10 @@ def main():
         order = sorted(range(len(lst)), key=lambda i: lst[i]["elapsed"])
         return lst[order[len(order) // 2]]
     meds = {pl: median_of(v) for pl, v in by_plan.items()}
-    plan = min(meds, key=lambda pl: meds[pl]["elapsed"])       # identical on every rank: the times are all-reduced
+    # The headline plan is fixed BY RULE, not picked by the measurement (a minimum over two noisy medians would be biased
+    # low and could flip from run to run): chains whenever the batch qualifies for them (>= 4 waves per SIMD, see
+    # use_chains), one launch per step otherwise.  With --launch auto the other plan is still timed and reported.
+    plan = plans[0]
     reps, med = by_plan[plan], meds[plan]
     elapsed, kern_ms, launches = med["elapsed"], med["kern_ms"], med["launches"]
     single = None
@@ -421,12 +480,13 @@ def main():
                        (stepper.n_chains, stepper.n_chains, stepper.n_chains, "" if args.no_stagger else ", chain c starts c/C of a step late (mvrl_delay_dev)")
                        if stepper_used is not None else "one launch per step")
         if len(plans) > 1:
-            launch_desc += "; chosen by measurement among " + ", ".join(
+            launch_desc += "; headline plan fixed by rule (chains when the batch has >= 4 waves per SIMD); timed: " + ", ".join(
                 "%s %.1f us/step" % (pl, meds[pl]["elapsed"] / K * 1e6) for pl in plans)
         out = {
             "metric": "env-steps/sec (whole node) + achieved HBM GB/s, 6-DoF batch", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "launch_plan": plan,
             "timing": {"repeats": len(reps), "statistic": "median repeat of the K-step region (max over ranks per repeat)",
                        "ms_per_step_repeats": [r_["elapsed"] / K * 1e3 for r_ in reps],
                        "launch_plans": {pl: {"ms_per_step": meds[pl]["elapsed"] / K * 1e3,
