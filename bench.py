@@ -495,6 +495,9 @@ def main():
             "config": {"workload": wl["name"], "envs_per_gpu": n, "global_envs": world * n, "dt": 0.02 if wl["model"].startswith("auv") else 0.2,
                        "n_substeps": args.n_substeps, "control_mode": args.control_mode, "episode_len": 250,
                        "kernel": env.variant,
+                       "kernel_compiler": (("ahead of time: hipcc, build.py" if not env.jit["specialized"] else
+                                            "run time: %s, %d VGPR, %d SGPR spills, %d B scratch" % (
+                                                env.jit["compiler"], env.jit["vgprs"], env.jit["sgpr_spills"], env.jit["scratch_bytes"]))),
                        "actions": ("PDController evaluated inside the episode kernel" if pd_obj is not None else
                                    "PDController kernel on the previous observation" if loop_objs is not None else
                                    f"ring of {RING} pre-generated uniform(-1,1) batches in HBM"),

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MVRL_ABI_VERSION 1
+#define MVRL_ABI_VERSION 2
 
 /* ---- models (which reference environment the handle replaces) ------------------------------ */
 #define MVRL_MODEL_AUV 0  /* AuvEnv, explicit Euler + turbulence current   tag/verySimpleAuv.py:76-416 */
@@ -290,6 +290,26 @@ int mvrl_derivs_f64(mvrl_handle* h, int64_t n, const double* t, const double* y,
  * two kernel names and which compiler produced them. ---- */
 int mvrl_specialize(mvrl_handle* h);
 int mvrl_jit_compile_check(const mvrl_rov6_params* params, int control_mode, size_t* code_size, char* log_buf, size_t log_cap);
+/* What mvrl_specialize built for this handle, read from the AMDGPU metadata note of the code object it loaded: which compiler
+ * ("hipcc", "hiprtc"; "none" = the handle runs an ahead-of-time kernel), the register budget it was compiled for, and the worse of
+ * the two instances' (turbulence off / on) register, spill and scratch figures (-1 = not in the note).  A build with spills
+ * (the in-process hiprtc of a process that loaded an older comgr produces them: DESIGN.md section 5) runs 8-20 % slower than the
+ * ahead-of-time kernel; MarineVecEnv warns about it.  mvrl_jit_compile_check2 = mvrl_jit_compile_check + that report (no GPU).
+ * mvrl_jit_child_env: the environment the hipcc child process is started with, one KEY=value per line - the parent's minus
+ * LD_PRELOAD / LD_AUDIT / ROCP_* / ROCPROFILER_* / HSA_TOOLS_* ..., so that a profiler attached to the host process does not
+ * follow into the compiler. */
+typedef struct mvrl_jit_report {
+    int32_t specialized;        /* 1 = a run-time compiled kernel is in use */
+    int32_t min_waves_per_simd; /* launch bound of the build that was kept (4, or 3 / 2 when the 128-VGPR build spilled) */
+    int32_t vgprs, sgprs;
+    int32_t vgpr_spills, sgpr_spills;
+    int32_t scratch_bytes, lds_bytes;
+    int64_t code_bytes;
+    char compiler[16];
+} mvrl_jit_report;
+int mvrl_jit_info(const mvrl_handle* h, mvrl_jit_report* out);
+int mvrl_jit_compile_check2(const mvrl_rov6_params* params, int control_mode, mvrl_jit_report* report, char* log_buf, size_t log_cap);
+int mvrl_jit_child_env(char* buf, size_t cap);
 
 /* ---- unit-level operators of the 6-DoF vehicle for n independent tuples (host arrays; NULL inputs / outputs are skipped), each
  * evaluated by the device functions the step kernel runs - the public methods example_trialTrajectories.py:100-134 and the

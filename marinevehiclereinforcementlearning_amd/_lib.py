@@ -29,6 +29,7 @@ SYMBOLS = [
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
     "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64", "mvrl_vehicle_ops", "mvrl_vehicle_ops_f64", "mvrl_specialize", "mvrl_jit_compile_check",
+    "mvrl_jit_info", "mvrl_jit_compile_check2", "mvrl_jit_child_env",
     "mvrl_auv_pd_episodes_dev", "mvrl_rollout_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
@@ -107,6 +108,9 @@ def load(path=None):
     lib.mvrl_vehicle_ops.argtypes = [vp, i64] + [vp] * 8
     lib.mvrl_specialize.argtypes = [vp]
     lib.mvrl_jit_compile_check.argtypes = [vp, C.c_int, vp, vp, C.c_size_t]
+    lib.mvrl_jit_info.argtypes = [vp, C.POINTER(P.JitReport)]
+    lib.mvrl_jit_compile_check2.argtypes = [vp, C.c_int, C.POINTER(P.JitReport), vp, C.c_size_t]
+    lib.mvrl_jit_child_env.argtypes = [vp, C.c_size_t]
     lib.mvrl_vehicle_ops_f64.argtypes = [vp, i64] + [vp] * 8
     lib.mvrl_rollout_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.mvrl_auv_pd_episodes_dev.argtypes = [vp, vp, vp, C.c_double, i32, vp, vp, vp]
@@ -305,6 +309,13 @@ class Handle:
         """Compile the 6-DoF step kernel for this handle's constants (hipcc child process, hiprtc fallback) and switch to it (mvrl_specialize)."""
         check(self.lib.mvrl_specialize(self.h), self.h)
         return self.variant
+
+    def jit_info(self):
+        """What mvrl_specialize built (mvrl_jit_info): dict(compiler, specialized, min_waves_per_simd, vgprs, sgprs, vgpr_spills,
+        sgpr_spills, scratch_bytes, lds_bytes, code_bytes); compiler "none" for an ahead-of-time kernel."""
+        rep = P.JitReport()
+        check(self.lib.mvrl_jit_info(self.h, C.byref(rep)), self.h)
+        return rep.as_dict()
 
     def enable_aux(self, on=True):
         check(self.lib.mvrl_enable_aux(self.h, 1 if on else 0), self.h)

@@ -64,17 +64,39 @@ __device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6
     float e[6];
     e[0] = sp[0] - y[0]; e[1] = sp[1] - y[1]; e[2] = sp[2] - y[2];
     e[3] = sp[3] - y[3]; e[4] = sp[4] - y[4];
+#if !MVRL_F64 && !defined(MVRL_NO_YAW_INC)
+    // Yaw error (resources.angleError, resources.py:75-95).  Inside an env step the set-point is constant, so the error of
+    // this call is the previous call's minus the yaw increment, wrapped back into [-pi, pi) when it leaves: 7 instructions
+    // instead of the 14 of a fresh range reduction plus the branch-consistency test - and the PID's difference e - eOld is
+    // then -dpose exactly, or -dpose -+ 2 pi across the wrap, which is what the reference's two wrapped errors differ by.
+    // The first call of an env step (new set-point; inc_valid false, wave-uniform) reduces afresh, which also re-anchors
+    // the chain: at most 16 roundings of 1e-7 accumulate.
+    float yaw_w = 0.f;
+    if (USE_INC && inc_valid) {
+        const float r1 = s.eold[5] - dpose[5];
+        yaw_w = (r1 >= MVRL_PI) ? -MVRL_TWO_PI_HI : ((r1 < -MVRL_PI) ? MVRL_TWO_PI_HI : 0.f);
+        e[5] = r1 + yaw_w;
+    } else {
+        e[5] = angle_error(sp[5], y[5]);
+    }
+#define MVRL_YAW_INC_ON 1
+#else
     e[5] = angle_error(sp[5], y[5]);
+#endif
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         float de = e[i] - s.eold[i];
         if (USE_INC) {
             // inc_valid is wave-uniform (false only for the first PID call of an env step, whose predecessor belongs to
             // the previous step).  x, y, z, phi, theta errors are plain differences sp - pose, so -dpose is their
-            // change; the yaw error can change branch (wrap at +-pi), which the consistency test detects.
+            // change; the yaw error can change branch (wrap at +-pi): its difference carries the wrap.
             const float di = -dpose[i];
+#ifdef MVRL_YAW_INC_ON
+            de = inc_valid ? ((i < 5) ? di : yaw_w + di) : de;
+#else
             const bool use = (i < 5) ? inc_valid : (inc_valid && fabsf(de - di) <= 1e-5f);
             de = use ? di : de;
+#endif
         }
         if (HAS_DT) s.eint[i] = fmaf(s.eold[i] + e[i], half_dtp, s.eint[i]);
         s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
@@ -307,7 +329,7 @@ __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, con
     t.sph = fmaf(b.cph, sd[0], b.sph * cd[0]); t.cph = fmaf(-b.sph, sd[0], b.cph * cd[0]);
     t.sth = fmaf(b.cth, sd[1], b.sth * cd[1]); t.cth = fmaf(-b.sth, sd[1], b.cth * cd[1]);
     t.sps = fmaf(b.cps, sd[2], b.sps * cd[2]); t.cps = fmaf(-b.sps, sd[2], b.cps * cd[2]);
-#ifndef MVRL_TRIG_WAVE_FALLBACK
+#if !defined(MVRL_TRIG_WAVE_FALLBACK) && !defined(MVRL_TRIG_NO_FALLBACK)   /* NO_FALLBACK: attribution builds only */
     // Lanes with a larger increment (an env spinning up next to gimbal lock: about one in a hundred under random actions)
     // take the full evaluation as a DIVERGENT branch: the wave issues those ~80 instructions with one or two lanes enabled.
     // The chip runs this kernel at its power limit, where an instruction's cost is the lanes it

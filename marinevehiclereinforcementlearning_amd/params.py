@@ -14,7 +14,7 @@ import numpy as np
 
 MODEL_AUV, MODEL_ROV3, MODEL_ROV6 = 0, 1, 2
 CTRL_FAITHFUL, CTRL_ZOH = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MODEL_NAMES = {"auv": MODEL_AUV, "rov3": MODEL_ROV3, "rov6": MODEL_ROV6}
 #            act, obs, init, state_words, aux
@@ -57,6 +57,18 @@ class AuvParams(C.Structure):
                 ("max_force", d), ("max_moment", d), ("x_min", d), ("x_max", d), ("y_min", d), ("y_max", d),
                 ("noise_mag_coeffs", d), ("noise_mag_actuation", d), ("stop_on_bounds", C.c_int32),
                 ("n_waypoints", C.c_int32), ("obs_scale", d * 9), ("wp_threshold", d), ("waypoints", d * (3 * 32))]
+
+
+class JitReport(C.Structure):
+    """mvrl_jit_report (include/mvrl.h): what mvrl_specialize built."""
+    _fields_ = [("specialized", C.c_int32), ("min_waves_per_simd", C.c_int32), ("vgprs", C.c_int32), ("sgprs", C.c_int32),
+                ("vgpr_spills", C.c_int32), ("sgpr_spills", C.c_int32), ("scratch_bytes", C.c_int32), ("lds_bytes", C.c_int32),
+                ("code_bytes", C.c_int64), ("compiler", C.c_char * 16)]
+
+    def as_dict(self):
+        out = {k: getattr(self, k) for k, _ in self._fields_}
+        out["compiler"] = self.compiler.decode()
+        return out
 
 
 class FlowDesc(C.Structure):

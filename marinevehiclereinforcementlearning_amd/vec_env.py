@@ -112,6 +112,13 @@ class MarineVecEnv:
             except _lib.MvrlError as e:   # no compiler on this machine: the ahead-of-time kernel keeps running
                 import warnings
                 warnings.warn(f"mvrl_specialize failed, keeping the run-time-constant kernel ({self._h.variant}): {e}")
+        self.jit = self._h.jit_info()     # compiler / registers / spills of a run-time compiled kernel ("none": ahead of time)
+        if self.jit["specialized"] and (self.jit["scratch_bytes"] > 0 or self.jit["sgpr_spills"] > 0 or self.jit["vgpr_spills"] > 0):
+            import warnings
+            warnings.warn(f"mvrl_specialize: the {self.jit['compiler']} build of the step kernel spills ({self.jit['sgpr_spills']} SGPR, "
+                          f"{self.jit['vgpr_spills']} VGPR, {self.jit['scratch_bytes']} B scratch at {self.jit['min_waves_per_simd']} waves per SIMD) - "
+                          "expect it 8-20 % slower than the ahead-of-time kernels; an in-process hiprtc older than the ROCm "
+                          "installation's hipcc does that (set MVRL_HIPCC / MVRL_JIT_COMPILER=hipcc)")
         self.flow = flow
         if use_flow:
             if self.model == P.MODEL_AUV:

@@ -134,3 +134,64 @@ def test_jit_specialisation_with_either_compiler(monkeypatch):
     size, log = C.c_size_t(0), C.create_string_buffer(8192)
     assert lib.mvrl_jit_compile_check(C.addressof(p6), P.CTRL_FAITHFUL, C.addressof(size), log, len(log)) != 0
     assert "cannot start" in log.value.decode() or "failed" in log.value.decode()
+
+
+def test_jit_child_environment_is_scrubbed(monkeypatch, tmp_path):
+    """The hipcc child of mvrl_specialize must not inherit a profiler: under rocprofv3 the host process carries LD_PRELOAD /
+    ROCP_TOOL_LIBRARIES / HSA_TOOLS_LIB, the tool library would initialise the GPU inside hipcc, and hipcc execs clang and lld -
+    exec after GPU initialisation.  mvrl_jit_child_env shows the environment the child gets; a compilation still succeeds with a
+    (dummy) profiler environment set, because the child never sees it."""
+    import ctypes as C
+    from marinevehiclereinforcementlearning_amd import _lib, params as P
+    lib = _lib.load()
+    for k, v in (("LD_PRELOAD", "/nonexistent/librocprofiler-sdk-tool.so"), ("ROCP_TOOL_LIBRARIES", "/nonexistent/tool.so"),
+                 ("HSA_TOOLS_LIB", "/nonexistent/libtool.so"), ("ROCPROFILER_LIBRARY_CTOR", "1"), ("LD_AUDIT", "/nonexistent/audit.so"),
+                 ("MVRL_KEEP_ME", "yes")):
+        # straight into the C environment (os.putenv): the test process itself must not start children with LD_PRELOAD set
+        C.CDLL(None).setenv(k.encode(), v.encode(), 1)
+    try:
+        buf = C.create_string_buffer(1 << 18)
+        assert lib.mvrl_jit_child_env(buf, len(buf)) == 0
+        keys = [ln.split("=", 1)[0] for ln in buf.value.decode().splitlines()]
+        assert "MVRL_KEEP_ME" in keys and "PATH" in keys
+        for k in keys:
+            assert not k.startswith(("LD_PRELOAD", "LD_AUDIT", "ROCP_", "ROCPROFILER_", "HSA_TOOLS_")), k
+        C.CDLL(None).setenv(b"MVRL_JIT_COMPILER", b"hipcc", 1)
+        C.CDLL(None).setenv(b"TMPDIR", str(tmp_path).encode(), 1)      # the scratch directory honours $TMPDIR ...
+        p6 = P.rov6_params(m=12.0, Xuu=-19.0)
+        rep, log = P.JitReport(), C.create_string_buffer(8192)
+        rc = lib.mvrl_jit_compile_check2(C.addressof(p6), P.CTRL_FAITHFUL, C.byref(rep), log, len(log))
+        assert rc == 0, log.value.decode()
+        assert os.listdir(tmp_path) == []                                # ... and is removed afterwards
+    finally:
+        for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_CTOR", "LD_AUDIT", "MVRL_KEEP_ME",
+                  "MVRL_JIT_COMPILER", "TMPDIR"):
+            C.CDLL(None).unsetenv(k.encode())
+
+
+def test_jit_report_reads_the_code_object_notes(monkeypatch):
+    """mvrl_jit_compile_check2 / mvrl_jit_info: compiler, registers, spills and scratch of what was built, parsed from the
+    AMDGPU metadata note.  The installation's hipcc fits the structured kernel into the 128-VGPR budget without scratch."""
+    import ctypes as C
+    from marinevehiclereinforcementlearning_amd import _lib, params as P
+    lib = _lib.load()
+    p6 = P.rov6_params(m=12.0, Xuu=-19.0)
+    got = {}
+    for compiler in ("hipcc", "hiprtc"):
+        monkeypatch.setenv("MVRL_JIT_COMPILER", compiler)
+        rep, log = P.JitReport(), C.create_string_buffer(8192)
+        assert lib.mvrl_jit_compile_check2(C.addressof(p6), P.CTRL_FAITHFUL, C.byref(rep), log, len(log)) == 0, log.value.decode()
+        r = rep.as_dict()
+        got[compiler] = r
+        assert r["compiler"] == compiler and r["specialized"] == 1 and r["min_waves_per_simd"] == 4
+        assert 64 <= r["vgprs"] <= 128 and 16 <= r["sgprs"] <= 112 and r["lds_bytes"] == 10240 and r["code_bytes"] > 10000
+        assert r["vgpr_spills"] >= 0 and r["sgpr_spills"] >= 0 and r["scratch_bytes"] >= 0
+    assert got["hipcc"]["scratch_bytes"] == 0 and got["hipcc"]["vgpr_spills"] == 0 and got["hipcc"]["sgpr_spills"] == 0, got
+
+
+def test_library_does_not_link_hiprtc_at_load_time(lib):
+    """hiprtc is the fallback compiler of an optional feature: dlopen-ed on first use, not a DT_NEEDED of libmvrl.so."""
+    import subprocess
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    needed = [ln for ln in out.splitlines() if "NEEDED" in ln]
+    assert needed and not any("hiprtc" in ln for ln in needed), needed

@@ -6,8 +6,10 @@
 # The counter passes (one rocprofv3 run per group, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE separately)
 # need per-launch values only: 200 steps, one launch per step (--chains 1), so that one dispatch = one env step of the batch.
 # Raw output lands under gpurun_out/prof_<tag>_*; tools/summarize_counters.py condenses it into profiles/.
+# `--specialize` arguments are fine under the profiler: the hipcc child of mvrl_specialize gets a scrubbed environment (no
+# LD_PRELOAD / ROCP_* / HSA_TOOLS_*: mvrl_abi.hip child_environment), so the tool library does not follow into the compiler.
 WL=${1:-c4}
-TAG=${2:-r02_$WL}
+TAG=${2:-r03_$WL}
 shift 2
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out

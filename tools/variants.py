@@ -32,6 +32,8 @@ VARIANTS = {
     "w2": dict(extra=["-DMVRL_MIN_WAVES=2"], drop=()),
     "w3": dict(extra=["-DMVRL_MIN_WAVES=3"], drop=()),
     "w4": dict(extra=["-DMVRL_MIN_WAVES=4"], drop=()),                # spills
+    "noyaw": dict(extra=["-DMVRL_NO_YAW_INC"], drop=()),              # fresh angle reduction of the yaw error at every PID call (round-2 behaviour)
+    "nofb": dict(extra=["-DMVRL_TRIG_NO_FALLBACK"], drop=()),         # attribution only: no full sincos for lanes with large angle increments
     "ilp": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp"], drop=()),
     "bias0": dict(extra=["-mllvm", "-amdgpu-schedule-metric-bias=0"], drop=()),
     "ilpw3": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-DMVRL_MIN_WAVES=3"], drop=()),
