@@ -325,6 +325,11 @@ int mvrl_vehicle_ops(mvrl_handle* h, int64_t n, const float* angles, const float
 int mvrl_vehicle_ops_f64(mvrl_handle* h, int64_t n, const double* angles, const double* gcf, const double* rpm_in, const double* vel,
                          double* axes, double* rpm_out, double* rhs, double* thruster_h);
 
+/* forceModel(pos, angles, vel, rpms, retComp=True) (6DoF.py:253, :401-402): comp[n, 6, 5] = columns -Crb.vel, -Ca.vel, -D.vel, G, H
+ * (H = A . thrusterModel(limit(rpm))) for n independent tuples; angles[n,3], vel[n,6], rpm_in[n,8]. */
+int mvrl_force_components(mvrl_handle* h, int64_t n, const float* angles, const float* vel, const float* rpm_in, float* comp);
+int mvrl_force_components_f64(mvrl_handle* h, int64_t n, const double* angles, const double* vel, const double* rpm_in, double* comp);
+
 /* Per-step side outputs the reference keeps in timeHistory (6DoF.py:578-587: F0..F5, u0..u7; 3DoF: F0..F2,u0..u3;
  * verySimpleAuv.py:389-403: Fx,Fy,N,u_current,v_current,rmsAc,r0..r4).  Enable BEFORE stepping;
  * aux row = [n_envs, aux_dim] f32 with aux_dim = 14 (ROV6) / 7 (ROV3) / 11 (AUV). */

@@ -29,7 +29,7 @@ SYMBOLS = [
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
     "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64", "mvrl_vehicle_ops", "mvrl_vehicle_ops_f64", "mvrl_specialize", "mvrl_jit_compile_check",
-    "mvrl_jit_info", "mvrl_jit_compile_check2", "mvrl_jit_child_env",
+    "mvrl_jit_info", "mvrl_jit_compile_check2", "mvrl_jit_child_env", "mvrl_force_components", "mvrl_force_components_f64",
     "mvrl_auv_pd_episodes_dev", "mvrl_rollout_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
@@ -112,6 +112,8 @@ def load(path=None):
     lib.mvrl_jit_compile_check2.argtypes = [vp, C.c_int, C.POINTER(P.JitReport), vp, C.c_size_t]
     lib.mvrl_jit_child_env.argtypes = [vp, C.c_size_t]
     lib.mvrl_vehicle_ops_f64.argtypes = [vp, i64] + [vp] * 8
+    lib.mvrl_force_components.argtypes = [vp, i64] + [vp] * 4
+    lib.mvrl_force_components_f64.argtypes = [vp, i64] + [vp] * 4
     lib.mvrl_rollout_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.mvrl_auv_pd_episodes_dev.argtypes = [vp, vp, vp, C.c_double, i32, vp, vp, vp]
     lib.mvrl_replay_add_sym_dev.argtypes = [i32] + [vp] * 5 + [i64] + [vp] * 6 + [i64, i64, i32, i32, vp]
@@ -303,6 +305,16 @@ class Handle:
             return None if a is None else a.ctypes.data
         check(self._fn("mvrl_vehicle_ops")(self.h, n, ang.ctypes.data, p(g), p(r), p(v), p(out.get("axes")), p(out.get("rpm")),
                                            p(out.get("rhs")), p(out.get("thruster_h"))), self.h)
+        return out
+
+    def force_components(self, angles, vel, rpm):
+        """forceModel(..., retComp=True) for n tuples: [n, 6, 5] = columns -Crb.vel, -Ca.vel, -D.vel, G, H (mvrl_force_components)."""
+        ang = np.ascontiguousarray(angles, self.dtype).reshape(-1, 3)
+        n = len(ang)
+        v = np.ascontiguousarray(vel, self.dtype).reshape(n, 6)
+        r = np.ascontiguousarray(rpm, self.dtype).reshape(n, 8)
+        out = np.zeros((n, 6, 5), self.dtype)
+        check(self._fn("mvrl_force_components")(self.h, n, ang.ctypes.data, v.ctypes.data, r.ctypes.data, out.ctypes.data), self.h)
         return out
 
     def specialize(self):

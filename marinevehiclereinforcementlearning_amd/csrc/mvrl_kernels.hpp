@@ -9,6 +9,8 @@ hipError_t launch_rov6_step(const Rov6Dev* p_dev, const StepIO& io, const FlowDe
 hipError_t launch_rov6_derivs(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* t, const float* y, const float* sp,
                               float* eold, float* eint, float* told, const uint8_t* has_old, float* dy, float* aux,
                               hipStream_t stream);
+hipError_t launch_rov6_components(const Rov6Dev* p, int64_t n, const float* angles, const float* vel, const float* rpm_in, float* comp,
+                                  hipStream_t stream);
 hipError_t launch_rov6_unit(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* angles, const float* gcf,
                             const float* rpm_in, const float* vel, float* axes, float* rpm_out, float* rhs, float* h_out,
                             hipStream_t stream);

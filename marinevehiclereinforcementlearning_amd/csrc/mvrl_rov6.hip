@@ -982,6 +982,70 @@ __global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov6_unit_kernel(const Rov6De
     }
 }
 
+// forceModel(..., retComp=True) (6DoF.py:401-402): the 6 x 5 breakdown [-Crb nu, -Ca nu, -D nu, G, H] for n independent
+// (attitude, velocity, rpm) tuples, row-major [n, 6, 5] - the literal dense matrices of 6DoF.py:303-388 from the handle's
+// run-time constants (every flavour keeps the full Rov6Dev in device memory), thrusters through limit_force like the step
+// kernel.  Unit-level entry point (mvrl_force_components), not a throughput path.
+__global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov6_components_kernel(const Rov6Dev* __restrict__ pg, int64_t n, const float* angles,
+                                                                          const float* vel_in, const float* rpm_in, float* comp) {
+    const CP6 p = as_const(pg);
+    const int64_t i = (int64_t)blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float ang[12] = {0.f, 0.f, 0.f, angles[i * 3], angles[i * 3 + 1], angles[i * 3 + 2], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const Trig6 t = trig6(ang);
+    float vel[6], F[8];
+#pragma unroll
+    for (int k = 0; k < 6; k++) vel[k] = vel_in[i * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float r = rpm_in[i * 8 + k] * (1.0f / 60.f);
+        F[k] = limit_force(p, p->thrust_k * r * r * fsign(r));
+    }
+    const float u = vel[0], v = vel[1], w = vel[2], pp = vel[3], q = vel[4], r = vel[5];
+    const float m = p->m, xg = p->cg[0], yg = p->cg[1], zg = p->cg[2];
+    const float Ixx = p->I[0], Ixy = p->I[1], Ixz = p->I[2], Iyy = p->I[4], Iyz = p->I[5], Izz = p->I[8];
+    const float Crb[36] = {
+        0, 0, 0, m * (yg * q + zg * r), -m * (xg * q - w), -m * (xg * r + v),
+        0, 0, 0, -m * (yg * pp + w), m * (zg * r + xg * pp), -m * (yg * r - u),
+        0, 0, 0, -m * (zg * pp - v), -m * (zg * q + u), m * (xg * pp + yg * q),
+        -m * (yg * q + zg * r), m * (yg * pp + w), m * (zg * pp - v), 0, -Iyz * q - Ixz * pp + Izz * r, Iyz * r + Ixy * pp - Iyy * q,
+        m * (xg * q - w), -m * (zg * r + xg * pp), m * (zg * q + u), Iyz * q + Ixz * pp - Izz * r, 0, -Ixz * r - Ixy * q + Ixx * pp,
+        m * (xg * r + v), m * (yg * r - u), -m * (xg * pp + yg * q), -Iyz * r - Ixy * pp + Iyy * q, Ixz * r + Ixy * q - Ixx * pp, 0};
+    const float Xud = p->added[0], Yvd = p->added[1], Zwd = p->added[2], Kpd = p->added[3], Mqd = p->added[4], Nrd = p->added[5];
+    const float Ca[36] = {
+        0, 0, 0, 0, -Zwd * w, Yvd * v,
+        0, 0, 0, Zwd * w, 0, -Xud * u,
+        0, 0, 0, -Yvd * v, Xud * u, 0,
+        0, -Zwd * w, Yvd * v, 0, -Nrd * r, Mqd * q,
+        Zwd * w, 0, -Xud * u, Nrd * r, 0, -Kpd * pp,
+        -Yvd * v, Xud * u, 0, -Mqd * q, Kpd * pp, 0};
+    const float G[6] = {p->wb * t.sth, -p->wb * t.cth * t.sph, -p->wb * t.cth * t.cph,
+                        -p->gw[1] * t.cth * t.cph + p->gw[2] * t.cth * t.sph,
+                        p->gw[2] * t.sth + p->gw[0] * t.cth * t.cph,
+                        -p->gw[0] * t.cth * t.sph - p->gw[1] * t.sth};
+    float* out = comp + i * 30;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        float c1 = 0.f, c2 = 0.f, c3 = 0.f, hh = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            c1 = fmaf(Crb[6 * a + j], vel[j], c1);
+            c2 = fmaf(Ca[6 * a + j], vel[j], c2);
+            c3 = fmaf(fmaf(p->dquad[6 * a + j], fabsf(vel[j]), p->dlin[6 * a + j]), vel[j], c3);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) hh = fmaf(p->A[8 * a + k], F[k], hh);
+        out[5 * a + 0] = -c1; out[5 * a + 1] = -c2; out[5 * a + 2] = -c3; out[5 * a + 3] = G[a]; out[5 * a + 4] = hh;
+    }
+}
+
+hipError_t launch_rov6_components(const Rov6Dev* p, int64_t n, const float* angles, const float* vel, const float* rpm_in, float* comp,
+                                  hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
+    hipLaunchKernelGGL(rov6_components_kernel, grid, block, 0, stream, p, n, angles, vel, rpm_in, comp);
+    return hipGetLastError();
+}
+
 hipError_t launch_rov6_unit(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* angles, const float* gcf,
                             const float* rpm_in, const float* vel, float* axes, float* rpm_out, float* rhs, float* h_out,
                             hipStream_t stream) {

@@ -61,6 +61,22 @@ def run_episodes(agent, env, episodes=1, step_cap=None, init=None, out_dir=None,
     return EpisodeSummary(scores, lengths, float(np.mean(scores)), float(np.median(scores)), files)
 
 
+def evaluate_agent(agent, env, num_episodes=1, num_steps=None, deterministic=True, num_last_for_reward=None, render=False, init=None,
+                   saveDir=None):
+    """Call-compatible with the reference's evaluation helper (tag/resources.py:49-102): same arguments, returns
+    (mean, median, all_episode_rewards) and writes <saveDir>/ep_<k>.csv - a thin adapter over run_episodes.  `render` is
+    accepted for signature compatibility; the environments' render() is a no-op (verySimpleAuv.py:412-416), so no frames."""
+    score = "sum" if num_last_for_reward is None else ("mean_last", num_last_for_reward)
+    s = run_episodes(agent, env, episodes=num_episodes, step_cap=num_steps, init=init, out_dir=saveDir, score=score,
+                     deterministic=deterministic)
+    print("  Mean reward:  ", s.mean)
+    print("  Median reward:", s.median)
+    print("  Num episodes: ", num_episodes)
+    if render:
+        return [], s.mean, s.median, s.scores
+    return s.mean, s.median, s.scores
+
+
 AUV_COLUMNS = (["step", "time", "reward", "x", "y", "psi", "x_d", "y_d", "psi_d", "Fx", "Fy", "N", "Fx_set", "Fy_set",
                 "N_set", "u", "v", "r", "u_current", "v_current", "rmsAc"] + [f"r{i}" for i in range(5)]
                + [f"a{i}" for i in range(3)] + [f"s{i}" for i in range(11)])

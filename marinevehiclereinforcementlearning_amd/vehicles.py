@@ -66,6 +66,7 @@ class BlueROV2Heavy6DoF(_Vehicle):
         self.controller = controller
         self._open(precision, **overrides)
         self._angles = np.zeros(3)
+        self.rotation_angles = np.zeros(3)
         self.iHat, self.jHat, self.kHat = np.eye(3)
         self.controlVector = np.zeros(8)
 
@@ -75,6 +76,7 @@ class BlueROV2Heavy6DoF(_Vehicle):
     # ---- the vehicle's other public methods, evaluated on the GPU through mvrl_vehicle_ops -----------------------------------
     def updateMovingCoordSystem(self, rotation_angles):
         """6DoF.py:238-242: sets iHat, jHat, kHat for the XYZ-intrinsic attitude."""
+        self.rotation_angles = rotation_angles            # 6DoF.py:240: the stored orientation is a public attribute
         self._angles = np.asarray(rotation_angles, np.float64)
         ax = self._h.vehicle_ops(self._angles[None], want=("axes",))["axes"][0].astype(np.float64)
         self.iHat, self.jHat, self.kHat = ax[0], ax[1], ax[2]
@@ -93,8 +95,13 @@ class BlueROV2Heavy6DoF(_Vehicle):
         self.controlVector = r["rpm"][0].astype(np.float64)
         return self.controlVector
 
-    def forceModel(self, pos, angles, vel, controlVector):
-        """6DoF.py:253-404: (M, RHS) for the given attitude, body velocities and thruster rpm."""
+    def forceModel(self, pos, angles, vel, rpms, retComp=False):
+        """6DoF.py:253-404: (M, RHS) for the given attitude, body velocities and thruster rpm; with retComp=True the 6 x 5 breakdown
+        [-Crb.vel, -Ca.vel, -D.vel, G, H] (:401-402) instead."""
+        controlVector = rpms
+        if retComp:
+            return self._h.force_components(np.asarray(angles, np.float64)[None], np.asarray(vel, np.float64)[None],
+                                            np.asarray(rpms, np.float64)[None])[0].astype(np.float64)
         r = self._h.vehicle_ops(np.asarray(angles, np.float64)[None], rpm=np.asarray(controlVector, np.float64)[None],
                                 vel=np.asarray(vel, np.float64)[None], want=("rhs",))
         M = np.array(self._h.cfg.rov6.mass, dtype=np.float64).reshape(6, 6)

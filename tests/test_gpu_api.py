@@ -426,6 +426,15 @@ def test_run_episodes_csv_matches_reference_evaluation(tmp_path):
     agent.reset()                                     # forget oldObs: the reference run started with a fresh controller
     res2 = run_episodes(agent, env, episodes=1, init=init, score=("mean_last", 10))
     assert abs(res2.scores[0] - float(np.mean(ref[-10:, list(g["columns"]).index("reward")]))) < 1e-3
+    # the reference's own call shape (tag/resources.py:49: evaluate_agent(agent, env, num_episodes, ..., init, saveDir) ->
+    # (mean, median, all)) through the adapter: same episode, same CSV
+    from marinevehiclereinforcementlearning_amd.history import evaluate_agent
+    np.random.seed(int(g["np_seed"]))
+    agent.reset()
+    sub = tmp_path / "adapter"
+    mean, median, allr = evaluate_agent(agent, env, num_episodes=1, init=init, saveDir=str(sub))
+    assert mean == median == allr[0] and abs(mean - res.mean) < 1e-9 * abs(res.mean)
+    assert np.array_equal(pandas.read_csv(sub / "ep_0.csv").to_numpy(), df.to_numpy())
     env.close(); agent.close()
 
 

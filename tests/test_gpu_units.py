@@ -183,6 +183,21 @@ def test_force_model_golden(precision, tol, flavour):
     h.close()
 
 
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-10), ("f32", 2e-5)])
+def test_force_model_components_golden(precision, tol):
+    """G7: forceModel(..., retComp=True) (6DoF.py:401-402) - the 6 x 5 breakdown [-Crb.vel, -Ca.vel, -D.vel, G, H] the imported
+    reference returned, through mvrl_force_components; its columns also recombine into RHS (velCurrent = 0: :396)."""
+    g = golden("g07_force_model.npz")
+    h = handle(6, precision)
+    comp = h.force_components(g["angles"], g["vel"], g["rpm"])
+    assert comp.shape == g["comp"].shape
+    for c in range(5):
+        assert max_scaled_err(comp[:, :, c], g["comp"][:, :, c]) < tol, c
+    rhs = comp[:, :, 0] + comp[:, :, 1] + comp[:, :, 2] - comp[:, :, 3] + comp[:, :, 4]
+    assert max_scaled_err(rhs, g["RHS"]) < 4 * tol
+    h.close()
+
+
 def test_vehicle_ops_argument_checks():
     h3 = handle(3, "f32")
     with pytest.raises(_lib.MvrlError):
@@ -212,4 +227,7 @@ def test_vehicle_facade_public_methods():
         assert max_scaled_err(rov.allocateThrust() / 3500., g6["rpm"][i] / 3500.) < 1e-10
         M, rhs = rov.forceModel(np.zeros(3), g7["angles"][i], g7["vel"][i], g7["rpm"][i])
         assert max_scaled_err(rhs, g7["RHS"][i]) < 1e-10 and np.array_equal(M, g7["M"])
+        assert np.array_equal(rov.rotation_angles, g6["angles"][i])           # 6DoF.py:240
+        comp = rov.forceModel(np.zeros(3), g7["angles"][i], g7["vel"][i], g7["rpm"][i], retComp=True)
+        assert comp.shape == (6, 5) and max_scaled_err(comp, g7["comp"][i]) < 1e-10
     rov.close()
