@@ -270,8 +270,10 @@ int mvrl_set_state_f64(mvrl_handle* h, const double* buf, size_t n_elems);
  * Row-major host arrays: t[n], y[n,2*dof], sp[n,dof]; controller memory eold[n,dof], eint[n,dof], told[n] is read AND
  * updated exactly as the call mutates it; has_old[n] = 0 means controller.eOld is None (first call).  Outputs dy[n,2*dof]
  * and, if non-NULL, the side outputs gcf[n,dof] (controller demand; 3-DoF: resolved into the body frame as the
- * reference's timeHistory stores it) and rpm[n,8|4].  Zero current.  Rigid-body models only. ---- */
-int mvrl_derivs(mvrl_handle* h, int64_t n, const float* t, const float* y, const float* sp, float* eold, float* eint, float* told,
+ * reference's timeHistory stores it) and rpm[n,8|4].  Zero current.  Rigid-body models only.
+ * t and told are DOUBLE for both precisions (ABI 2): the controller uses t - tOld, which two fp32 times near t = 40 s resolve
+ * to 4e-6 only; an fp32 handle forms the difference in fp64 on the host and computes everything else in fp32. ---- */
+int mvrl_derivs(mvrl_handle* h, int64_t n, const double* t, const float* y, const float* sp, float* eold, float* eint, double* told,
                 const uint8_t* has_old, float* dy, float* gcf, float* rpm);
 int mvrl_derivs_f64(mvrl_handle* h, int64_t n, const double* t, const double* y, const double* sp, double* eold, double* eint,
                     double* told, const uint8_t* has_old, double* dy, double* gcf, double* rpm);

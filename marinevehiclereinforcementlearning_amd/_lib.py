@@ -268,11 +268,11 @@ class Handle:
         nthr = 8 if dof == 6 else 4
         y = np.ascontiguousarray(np.atleast_2d(y), self.dtype)
         n = y.shape[0]
-        t = np.ascontiguousarray(np.broadcast_to(np.asarray(t, self.dtype), (n,)))
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(t, np.float64), (n,)))      # times are fp64 at the ABI for both precisions
         sp = np.ascontiguousarray(np.atleast_2d(sp), self.dtype)
         eo = np.zeros((n, dof), self.dtype) if eold is None else np.array(np.atleast_2d(eold), self.dtype)
         ei = np.zeros((n, dof), self.dtype) if eint is None else np.array(np.atleast_2d(eint), self.dtype)
-        to = np.zeros(n, self.dtype) if told is None else np.array(np.broadcast_to(np.asarray(told, self.dtype), (n,)))
+        to = np.zeros(n, np.float64) if told is None else np.array(np.broadcast_to(np.asarray(told, np.float64), (n,)))
         ho = (np.zeros(n, np.uint8) if (has_old is None and eold is None) else
               np.ones(n, np.uint8) if has_old is None else np.ascontiguousarray(np.broadcast_to(has_old, (n,)), np.uint8))
         assert y.shape == (n, 2 * dof) and sp.shape == (n, dof) and eo.shape == (n, dof) and ei.shape == (n, dof)

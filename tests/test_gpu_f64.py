@@ -21,6 +21,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("name,dof,n_sub,mode", [
     ("g09_rk4_6dof_faithful_nsub4.npz", 6, 4, P.CTRL_FAITHFUL),
+    ("g09_rk4_6dof_faithful_nsub4_x64.npz", 6, 4, P.CTRL_FAITHFUL),      # 64 envs x 100 steps (SURVEY 8(c) G9's sample size)
+    ("g09_rk4_6dof_zoh_nsub4_x32.npz", 6, 4, P.CTRL_ZOH),                # 32 envs x 60 steps
     ("g09_rk4_6dof_faithful_nsub8.npz", 6, 8, P.CTRL_FAITHFUL),
     ("g09_rk4_6dof_zoh_nsub4.npz", 6, 4, P.CTRL_ZOH),
     ("g09_rk4_6dof_fixedsp_nsub4.npz", 6, 4, P.CTRL_FAITHFUL),

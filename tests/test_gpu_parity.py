@@ -34,6 +34,8 @@ def rov_init(g, dof):
 
 @pytest.mark.parametrize("name,dof,n_sub,mode", [
     ("g09_rk4_6dof_faithful_nsub4.npz", 6, 4, P.CTRL_FAITHFUL),
+    ("g09_rk4_6dof_faithful_nsub4_x64.npz", 6, 4, P.CTRL_FAITHFUL),      # 64 envs x 100 steps (SURVEY 8(c) G9's sample size)
+    ("g09_rk4_6dof_zoh_nsub4_x32.npz", 6, 4, P.CTRL_ZOH),                # 32 envs x 60 steps
     ("g09_rk4_6dof_faithful_nsub8.npz", 6, 8, P.CTRL_FAITHFUL),
     ("g09_rk4_6dof_faithful_nsub2.npz", 6, 2, P.CTRL_FAITHFUL),
     ("g09_rk4_6dof_zoh_nsub4.npz", 6, 4, P.CTRL_ZOH),
@@ -85,7 +87,10 @@ def test_reference_rk4_trajectories(oracle_mod, name, dof, n_sub, mode):
         assert max_scaled_err(st[3 * dof:4 * dof].T[on], g["eInt"][on, s]) < TOL, s
     print(name, audit.report())
     audit.assert_explained(max_smooth_share=1.0 / n_env)
-    assert audit.bad.sum() <= max(1, n_env // 8), audit.report()     # 16 envs x 40..200 steps: at most a couple leave
+    # envs that left the golden trajectory (each one explained above): at most twice what was measured on MI355X in round 3
+    # (gpurun_out/r3_s4_parity.log: 1 of 6, 2 of 64, none elsewhere), never a share of the batch
+    measured = {"g09_rk4_6dof_faithful_nsub4.npz": 1, "g09_rk4_6dof_faithful_nsub4_x64.npz": 2}.get(name, 0)
+    assert audit.bad.sum() <= max(1, 2 * measured), audit.report()
     h.close()
 
 

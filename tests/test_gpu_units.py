@@ -29,28 +29,53 @@ def test_derivs_goldens_fp64(dof):
     h.close()
 
 
+def _input_sensitivity(g, dof):
+    """A-priori bound on what fp32 INPUT resolution can do to the accelerations of one derivs call: the PID differentiates
+    e - eOld, four fp32 numbers (sp, pose, their difference, eOld) each resolved to half an ulp, and multiplies by K_D / max(1e-9,
+    t - tOld); the demand then passes rotation (norm-preserving), allocation + saturation (Lipschitz ||A|| ||pinv A||) and M^-1.
+    Nothing here is fitted to the kernel: constants from params.py, spacings from numpy."""
+    prm = P.rov6_params() if dof == 6 else P.rov3_params()
+    kd, minv = np.array(prm.kd), np.abs(np.array(prm.minv).reshape(dof, dof))
+    if dof == 6:
+        lip = np.linalg.norm(np.array(prm.alloc).reshape(6, 8), 2) * np.linalg.norm(np.array(prm.alloc_inv).reshape(8, 6), 2)
+    else:
+        ai = np.array(prm.alloc_inv).reshape(4, 3)
+        lip = np.linalg.norm(ai, 2) * np.linalg.norm(np.linalg.pinv(ai), 2)
+    ulp = lambda x: np.spacing(np.abs(np.asarray(x, np.float32))).astype(np.float64)
+    pose, e, eo = g["y"][:, :dof], g["eOld_out"], np.where(g["has_old"][:, None], g["eOld"], g["eOld_out"])
+    de = 0.5 * (ulp(g["sp"]) + ulp(pose) + ulp(e) + ulp(eo))
+    den = np.maximum(1e-9, g["t"] - g["tOld"])[:, None]
+    du = np.where(g["has_old"][:, None], kd[None] * de / den, 0.0)           # first calls differentiate against themselves: 0
+    half = dof // 2 if dof == 6 else 2
+    tau = np.concatenate([np.repeat(np.linalg.norm(du[:, :half], axis=1)[:, None], half, 1),
+                          np.repeat(np.linalg.norm(du[:, half:], axis=1)[:, None], dof - half, 1)], axis=1)
+    return lip * (tau @ minv.T).max(axis=1)
+
+
 @pytest.mark.parametrize("dof", [6, 3])
 def test_derivs_goldens_fp32(dof):
+    """G8 through the fp32 handle, EVERY case: t and tOld are fp64 at the ABI (t - tOld is formed in fp64 on the host), so what
+    separates an fp32 call from the reference is the resolution of its fp32 inputs, amplified by K_D / (t - tOld) - and mostly
+    swallowed by the clamp.  Every case must meet 1e-5, floor cases (t <= tOld) included; at most 2 % may exceed it, and only
+    if their a-priori input sensitivity (_input_sensitivity) explains the excess."""
     g = golden(f"g08_derivs{dof}.npz")
     h = handle(dof, "f32")
     assert "baked" in h.variant
     r = h.derivs(g["t"], g["y"], g["sp"], eold=g["eOld"], eint=g["eInt"], told=g["tOld"], has_old=g["has_old"])
-    # (e - eOld) / max(1e-9, t - tOld): with t - tOld <= 1e-9 the fp32 rounding of the INPUTS (1e-7) is multiplied by 1e9,
-    # so the clamped demand can sit on the other rail - an input-precision effect of this unit test, not of the kernels
-    # (inside a step the difference comes from the RK stage slopes).  Those cases are counted.
-    amplified = g["has_old"] & ((g["t"] - g["tOld"]) <= 1e-6)
-    ok = ~amplified
-    assert ok.sum() >= len(ok) // 3
-    # absolute times in fp32 resolve t - tOld to ~5e-7 only, and the accelerations are (K_D / dt) x (1 / inertia) x that:
-    # 2e-4 for the 6-DoF goldens (as the fp32 build of the oracle, tests/test_oracle_unit.py), 2e-3 for the 3-DoF ones
-    # (yaw inertia 0.28 kg m^2)
-    assert max_scaled_err(r["dy"][ok], g["dy"][ok]) < (2e-4 if dof == 6 else 2e-3)
-    umax = np.array([50., 50., 50., 1., 1., 2.] if dof == 6 else [150., 150., 100.])
-    assert np.max(np.abs(r["gcf"][ok] - g["gcf"][ok]) / umax) < 1e-3
-    assert max_scaled_err(r["eint"][ok], g["eInt_out"][ok]) < 1e-5
-    assert max_scaled_err(r["eold"], g["eOld_out"]) < 1e-5       # eOld' = e for every case
-    first = ~g["has_old"]                                          # first calls: dedt = 0 exactly -> tight
-    assert max_scaled_err(r["dy"][first], g["dy"][first]) < 1e-5
+    sens = _input_sensitivity(g, dof)
+    err = (np.abs(r["dy"].astype(np.float64) - g["dy"]) / np.maximum(1.0, np.abs(g["dy"]))).max(axis=1)
+    ok = err <= 1e-5
+    print(f"derivs{dof} fp32: {ok.sum()} of {len(ok)} G8 cases within 1e-5 (max {err[ok].max():.2e}); beyond it: "
+          f"{[(int(i), float(err[i]), float(sens[i])) for i in np.nonzero(~ok)[0]]}")
+    # every case meets the bar, save at most 2 % that the a-priori bound shows to be at the mercy of their inputs' last bit
+    assert np.all(ok | (err <= 4.0 * sens)), [(int(i), float(err[i]), float(sens[i])) for i in np.nonzero(~ok)[0]]
+    assert (~ok).sum() <= max(1, len(ok) // 50), int((~ok).sum())
+    assert max_scaled_err(r["eold"], g["eOld_out"]) < 1e-5                     # eOld' = e for every case
+    assert np.array_equal(r["told"], g["tOld_out"])                            # tOld' = t, exactly (fp64)
+    dt = g["t"] - g["tOld"]
+    smooth = ~(g["has_old"] & (dt <= 1e-6))
+    assert max_scaled_err(r["eint"][smooth], g["eInt_out"][smooth]) < 1e-5
+    first = ~g["has_old"]                                                      # first calls: dedt = 0 exactly -> tight, side outputs too
     assert max_scaled_err(r["rpm"][first] / 3500.0, g["rpm"][first] / 3500.0) < 1e-5
     h.close()
 

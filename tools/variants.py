@@ -17,6 +17,7 @@ VARIANTS = {
     "novs": dict(extra=["-DMVRL_NO_VGPR_SCALARS"], drop=()),          # RK step sizes left in SGPRs
     "auvscatter": dict(extra=["-DMVRL_AUV_LDS_OBS=0"], drop=()),      # AuvEnv observations stored row-per-lane
     "blk256": dict(extra=["-DMVRL_STEP_BLOCK=256"], drop=()),
+    "blk32": dict(extra=["-DMVRL_STEP_BLOCK=32"], drop=()),           # half-filled waves: twice the waves for a launch-bound batch (C2)
     "slp": dict(extra=[], drop=("-fno-slp-vectorize",)),
     "nofast": dict(extra=[], drop=("-ffast-math",)),
     "fulltrig": dict(extra=["-DMVRL_FULL_STAGE_TRIG"], drop=()),      # full sincos at every RK stage (round-1 behaviour)
