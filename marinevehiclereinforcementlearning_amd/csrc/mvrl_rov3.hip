@@ -18,19 +18,42 @@ struct Pid3 {
 // PID + body-frame resolution + allocation + saturation (3DoF.py:141-180) -> limited thruster forces F[4]
 // USE_INC / dpose: see pid6 in mvrl_rov6.hip - the error difference of two nearby RK stages is taken from the
 // stage slopes, not from the rounded fp32 states.
+// z: the pose in ERROR coordinates, z = setPoint - pose (yaw: the unwrapped difference) - see rov6_step_kernel in mvrl_rov6.hip.
+// e0 / fixed: with a fixed set-point the integrated variable is the displacement since the start of the step and the error is
+// e0 + z (see pid6 in mvrl_rov6.hip); `fixed` is wave-uniform.
 template <bool HAS_DT, bool USE_INC, class PP>
-__device__ __forceinline__ void control3(PP p, const float* y, const float* sp, Pid3& s, float dtp, float inv_den,
-                                         const float* dpose, bool inc_valid, float c, float sn, float* F, float* aux_row) {
+__device__ __forceinline__ void control3(PP p, const float* z, Pid3& s, float dtp, float inv_den,
+                                         const float* dpose, bool inc_valid, float c, float sn, float* F, float* aux_row,
+                                         bool fixed, const float* e0) {
     p = launder(p);
-    float e[3] = {sp[0] - y[0], sp[1] - y[1], angle_error(sp[2], y[2])};
+    float e[3] = {z[0], z[1], 0.f}, z2 = z[2];
+    if (fixed) { e[0] += e0[0]; e[1] += e0[1]; z2 += e0[2]; }
+#if !MVRL_F64 && !defined(MVRL_NO_YAW_INC)
+    // yaw error carried from call to call inside an env step (see pid6): previous error minus the yaw increment, wrapped
+    float yaw_w = 0.f;
+    if (USE_INC && inc_valid) {
+        const float r1 = s.eold[2] - dpose[2];
+        yaw_w = (r1 >= MVRL_PI) ? -MVRL_TWO_PI_HI : ((r1 < -MVRL_PI) ? MVRL_TWO_PI_HI : 0.f);
+        e[2] = r1 + yaw_w;
+    } else {
+        e[2] = angle_error(z2, 0.f);
+    }
+#define MVRL_YAW_INC3_ON 1
+#else
+    e[2] = angle_error(z2, 0.f);
+#endif
     float u[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         float de = e[i] - s.eold[i];
         if (USE_INC) {
             const float di = -dpose[i];
+#ifdef MVRL_YAW_INC3_ON
+            de = inc_valid ? ((i < 2) ? di : yaw_w + di) : de;
+#else
             const bool use = (i < 2) ? inc_valid : (inc_valid && fabsf(de - di) <= 1e-5f);
             de = use ? di : de;
+#endif
         }
         // dtp / 2 and K_D / dt are the same for every call of a step: loop-invariant products (literals x one register in the
         // baked flavour), hoisted by the compiler
@@ -70,8 +93,13 @@ __device__ __forceinline__ void dynamics3(PP p, const float* y, float c, float s
     float Xsum = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
+#if MVRL_F64
         float uJet = sqrtf(fabsf(F[i]) * p->inv_jet_area_k);
         float q = au / fmaxf(1e-5f, uJet);
+#else
+        // |u| / max(1e-5, uJet) = |u| * min(1e5, 1 / sqrt(|F| / k)): one v_rsq instead of v_sqrt + v_rcp (rsq(0) = inf -> 1e5)
+        float q = au * fminf(1e5f, __builtin_amdgcn_rsqf(fabsf(F[i]) * p->inv_jet_area_k));
+#endif
         float dCd = p->jet_c1 * expf(-p->jet_k1 * q) + p->jet_c2 * expf(-p->jet_k2 * q);
         Xsum += dCd * drag;
     }
@@ -98,14 +126,41 @@ __device__ __forceinline__ void dynamics3(PP p, const float* y, float c, float s
     dy[2] = r;
 }
 
+struct Trig1 {
+    float s, c;
+};
+__device__ __forceinline__ Trig1 trig1(float a) {
+    Trig1 t;
+    sincos_f32(a, t.s, t.c);
+    return t;
+}
+// sin / cos of the heading at an RK stage that differs from a known one by the small increment d (stage_trig in mvrl_rov6.hip):
+// rotation by short Taylor polynomials; a lane with |d| > 0.25 (and the fp64 build) evaluates sp_psi - z_psi in full.
+__device__ __forceinline__ Trig1 stage_trig1(const Trig1& b, float d, float sp_psi, float z_psi) {
+#if MVRL_F64 || defined(MVRL_FULL_STAGE_TRIG)
+    return trig1(sp_psi - z_psi);
+#else
+    const float r2 = d * d;
+    const float ps = fmaf(8.333333333e-3f, r2, -1.666666667e-1f);
+    const float sd = fmaf(ps * r2, d, d);
+    const float pc = fmaf(-1.388888889e-3f, r2, 4.166666667e-2f);
+    const float cd = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    Trig1 t;
+    t.s = fmaf(b.c, sd, b.s * cd);
+    t.c = fmaf(-b.s, sd, b.c * cd);
+    if (fabsf(d) > 0.25f) t = trig1(sp_psi - z_psi);
+    return t;
+#endif
+}
+
+// y: [error coordinates of the pose (3) | body velocities (3)]; t: sin / cos of the stage's heading
 template <bool FLOW, bool HAS_DT, class PP>
-__device__ __forceinline__ void derivs3(PP p, const float* y, const float* sp, Pid3& pid, float dtp, float inv_den,
-                                        const float* dpose, bool inc_valid, float2 cur, float* dy, float* aux_row) {
-    float sn, c;
-    sincos_f32(y[2], sn, c);
+__device__ __forceinline__ void derivs3(PP p, const float* y, const Trig1& t, Pid3& pid, float dtp, float inv_den,
+                                        const float* dpose, bool inc_valid, float2 cur, float* dy, float* aux_row, bool fixed,
+                                        const float* e0) {
     float F[4];
-    control3<HAS_DT, true>(p, y, sp, pid, dtp, inv_den, dpose, inc_valid, c, sn, F, aux_row);
-    dynamics3<FLOW>(p, y, c, sn, F, cur, dy);
+    control3<HAS_DT, true>(p, y, pid, dtp, inv_den, dpose, inc_valid, t.c, t.s, F, aux_row, fixed, e0);
+    dynamics3<FLOW>(p, y, t.c, t.s, F, cur, dy);
 }
 
 template <class PP>
@@ -221,12 +276,21 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     istep += 1;
     FlowTap tap;
     if (FLOW) tap = flow_gather(fl, (float)istep * io.dt + toff, y[0], y[1]);
+    // error coordinates (see rov6_step_kernel): the RK4 loop integrates z = setPoint - pose, which starts the step at a * scale
+    // (fixed set-point: z = pose_start - pose, starting at 0, and the controller adds e0 = setPoint - pose_start)
+    const bool fixed = io.fixed_sp != 0;
+    float z0[3], e0[3], org[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++)  // 3DoF.py:469-472
-        sp[k] = io.fixed_sp ? spin[k] : fmaf(spin[k], p->act_scale[k], y[k]);
+    for (int k = 0; k < 3; k++) {  // 3DoF.py:469-472
+        const float da = spin[k] * p->act_scale[k];
+        sp[k] = fixed ? spin[k] : da + y[k];
+        e0[k] = fixed ? spin[k] - y[k] : da;           // the error at the start of the step (yaw: unwrapped)
+        org[k] = fixed ? y[k] : sp[k];                 // pose = org - z
+        z0[k] = fixed ? 0.f : e0[k];
+    }
     float2 cur = make_float2(0.f, 0.f);
     if (FLOW) cur = flow_combine(tap);
-    if (first) { pid.eold[0] = sp[0] - y[0]; pid.eold[1] = sp[1] - y[1]; pid.eold[2] = angle_error(sp[2], y[2]); }
+    if (first) { pid.eold[0] = e0[0]; pid.eold[1] = e0[1]; pid.eold[2] = angle_error(e0[2], 0.f); }
 
     const float h_s = io.dt / (float)io.n_sub;
     const float h = in_vgpr(h_s), hh = in_vgpr(0.5f * h_s), h6 = in_vgpr(h_s / 6.f), inv_hh = in_vgpr(1.0f / (0.5f * h_s));
@@ -245,54 +309,65 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
         if (io.nfev) io.nfev[i_in] = nfev;
     } else
 #endif
+    {
+    Trig1 tb = trig1(y[2]);   // heading at the start of the step: the one full sincos of the step
+#pragma unroll
+    for (int q = 0; q < 3; q++) y[q] = z0[q];          // from here to the end of the loop y[0..2] is the ERROR setPoint - pose
+#define MVRL_AX3(c_, q_) ((q_) < 3 ? -(c_) : (c_))
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[6], acc[6], yt[6];
         float* const aux_last = (ks == io.n_sub - 1) ? aux_row : nullptr;
+        if (ks > 0 && (ZOH || (ks & 3) == 0)) tb = trig1(org[2] - y[2]);   // ZOH: every sub-step; FAITHFUL: re-anchored every fourth
         if (ZOH) {
-            float sn, c, F[4];
-            sincos_f32(y[2], sn, c);
-            if (first && ks == 0) control3<false, false>(p, y, sp, pid, 0.f, 1e9f, nullptr, false, c, sn, F, aux_last);
-            else control3<true, true>(p, y, sp, pid, h, 1.0f / h, inc_prev, ks > 0, c, sn, F, aux_last);
-            dynamics3<FLOW>(p, y, c, sn, F, cur, k);
+            float F[4];
+            if (first && ks == 0) control3<false, false>(p, y, pid, 0.f, 1e9f, nullptr, false, tb.c, tb.s, F, aux_last, fixed, e0);
+            else control3<true, true>(p, y, pid, h, 1.0f / h, inc_prev, ks > 0, tb.c, tb.s, F, aux_last, fixed, e0);
+            dynamics3<FLOW>(p, y, tb.c, tb.s, F, cur, k);
 #pragma unroll
-            for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
-            sincos_f32(yt[2], sn, c);
-            dynamics3<FLOW>(p, yt, c, sn, F, cur, k);
+            for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(MVRL_AX3(hh, q), k[q], y[q]); }
+            Trig1 t = stage_trig1(tb, hh * k[2], org[2], yt[2]);
+            dynamics3<FLOW>(p, yt, t.c, t.s, F, cur, k);
 #pragma unroll
-            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
-            sincos_f32(yt[2], sn, c);
-            dynamics3<FLOW>(p, yt, c, sn, F, cur, k);
+            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(MVRL_AX3(hh, q), k[q], y[q]); }
+            t = stage_trig1(tb, hh * k[2], org[2], yt[2]);
+            dynamics3<FLOW>(p, yt, t.c, t.s, F, cur, k);
 #pragma unroll
-            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
-            sincos_f32(yt[2], sn, c);
-            dynamics3<FLOW>(p, yt, c, sn, F, cur, k);
+            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(MVRL_AX3(h, q), k[q], y[q]); }
+            t = stage_trig1(tb, h * k[2], org[2], yt[2]);
+            dynamics3<FLOW>(p, yt, t.c, t.s, F, cur, k);
 #pragma unroll
             for (int q = 0; q < 3; q++) inc_prev[q] = h6 * (acc[q] + k[q]);
         } else {
             float dp[3], d2[3], d3[3];
 #pragma unroll
             for (int q = 0; q < 3; q++) dp[q] = inc_prev[q];
-            derivs3<FLOW, false>(p, y, sp, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr);
+            derivs3<FLOW, false>(p, y, tb, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr, fixed, e0);
 #pragma unroll
-            for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
+            for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(MVRL_AX3(hh, q), k[q], y[q]); }
 #pragma unroll
             for (int q = 0; q < 3; q++) dp[q] = hh * k[q];
-            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, dp, true, cur, k, nullptr);
+            derivs3<FLOW, true>(p, yt, stage_trig1(tb, dp[2], org[2], yt[2]), pid, hh, inv_hh, dp, true, cur, k, nullptr, fixed, e0);
 #pragma unroll
             for (int q = 0; q < 3; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }
 #pragma unroll
-            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
-            derivs3<FLOW, false>(p, yt, sp, pid, 0.f, 1e9f, dp, true, cur, k, nullptr);
+            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(MVRL_AX3(hh, q), k[q], y[q]); }
+            derivs3<FLOW, false>(p, yt, stage_trig1(tb, d2[2], org[2], yt[2]), pid, 0.f, 1e9f, dp, true, cur, k, nullptr, fixed, e0);
 #pragma unroll
             for (int q = 0; q < 3; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
 #pragma unroll
-            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
-            derivs3<FLOW, true>(p, yt, sp, pid, hh, inv_hh, dp, true, cur, k, aux_last);
+            for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(MVRL_AX3(h, q), k[q], y[q]); }
+            derivs3<FLOW, true>(p, yt, stage_trig1(tb, d3[2], org[2], yt[2]), pid, hh, inv_hh, dp, true, cur, k, aux_last, fixed, e0);
 #pragma unroll
             for (int q = 0; q < 3; q++) inc_prev[q] = h6 * (acc[q] + k[q]) - d3[q];
         }
+        const float dpsi = h6 * (acc[2] + k[2]);      // the sub-step's own heading increment
 #pragma unroll
-        for (int q = 0; q < 6; q++) y[q] = fmaf(h6, acc[q] + k[q], y[q]);
+        for (int q = 0; q < 6; q++) y[q] = fmaf(MVRL_AX3(h6, q), acc[q] + k[q], y[q]);
+        if (!ZOH && ((ks + 1) & 3) != 0 && ks + 1 < io.n_sub) tb = stage_trig1(tb, dpsi, org[2], y[2]);   // base of the next sub-step
+    }
+#undef MVRL_AX3
+#pragma unroll
+    for (int q = 0; q < 3; q++) y[q] = org[q] - y[q];   // back to the pose
     }
     y[2] = mod_two_pi(y[2]);  // 3DoF.py:480
     // The epilogue addresses the same SoA planes as the prologue.  Left alone, LLVM keeps all ~40 prologue

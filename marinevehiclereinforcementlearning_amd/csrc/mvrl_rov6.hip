@@ -57,13 +57,26 @@ __device__ __forceinline__ Axes body_axes(const Trig6& t) {
 //
 // half_dtp = (t - tOld) / 2 (trapezoidal integral); kd_inv[i] = K_D[i] / max(1e-9, t - tOld), formed once per env step by the
 // caller (null when !HAS_DT: the floor, K_D[i] * 1e9, a compile-time constant in the baked flavour).
-template <bool HAS_DT, bool USE_INC, class PP>
-__device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6& s, float half_dtp,
-                                     const float* kd_inv, const float* dpose, bool inc_valid, float* u) {
+//
+// z: the step kernel integrates the pose in ERROR coordinates - z[0..5] = setPoint - pose (yaw: the unwrapped difference), see
+// rov6_step_kernel - so the controller's error vector is its input, not a subtraction of two numbers of the size of the pose.
+// e0s / fixed: with a fixed set-point (6DoF.py:536-541) the error can be metres and radians large, so the integrated variable is
+// the DISPLACEMENT since the start of the step instead (it starts at 0) and the error is E0 + z, E0 = setPoint - pose at the start
+// of the step, parked in LDS; `fixed` is wave-uniform, the action mode pays one scalar branch.
+template <bool HAS_DT, bool USE_INC, class PP, class E0S>
+__device__ __forceinline__ void pid6(PP p, const float* z, Pid6& s, float half_dtp,
+                                     const float* kd_inv, const float* dpose, bool inc_valid, float* u, bool fixed, const E0S& e0s) {
     p = launder(p);  // phase-local scalar loads of the constants (see mvrl_device.hpp)
-    float e[6];
-    e[0] = sp[0] - y[0]; e[1] = sp[1] - y[1]; e[2] = sp[2] - y[2];
-    e[3] = sp[3] - y[3]; e[4] = sp[4] - y[4];
+    float e[6], z5 = z[5];
+    e[0] = z[0]; e[1] = z[1]; e[2] = z[2];
+    e[3] = z[3]; e[4] = z[4];
+    if (fixed) {
+        float e0[6];
+        e0s.get(e0);
+#pragma unroll
+        for (int i = 0; i < 5; i++) e[i] += e0[i];
+        z5 += e0[5];
+    }
 #if !MVRL_F64 && !defined(MVRL_NO_YAW_INC)
     // Yaw error (resources.angleError, resources.py:75-95).  Inside an env step the set-point is constant, so the error of
     // this call is the previous call's minus the yaw increment, wrapped back into [-pi, pi) when it leaves: 7 instructions
@@ -77,11 +90,11 @@ __device__ __forceinline__ void pid6(PP p, const float* y, const float* sp, Pid6
         yaw_w = (r1 >= MVRL_PI) ? -MVRL_TWO_PI_HI : ((r1 < -MVRL_PI) ? MVRL_TWO_PI_HI : 0.f);
         e[5] = r1 + yaw_w;
     } else {
-        e[5] = angle_error(sp[5], y[5]);
+        e[5] = angle_error(z5, 0.f);
     }
 #define MVRL_YAW_INC_ON 1
 #else
-    e[5] = angle_error(sp[5], y[5]);
+    e[5] = angle_error(z5, 0.f);
 #endif
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -294,13 +307,85 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
     dy[5] = icd * tq;
 }
 
-__device__ __forceinline__ Trig6 trig6(const float* y) {
+__device__ __forceinline__ Trig6 trig6_ang(float phi, float theta, float psi) {
     Trig6 t;
-    sincos_f32(y[3], t.sph, t.cph);
-    sincos_f32(y[4], t.sth, t.cth);
-    sincos_f32(y[5], t.sps, t.cps);
+    sincos_f32(phi, t.sph, t.cph);
+    sincos_f32(theta, t.sth, t.cth);
+    sincos_f32(psi, t.sps, t.cps);
     return t;
 }
+__device__ __forceinline__ Trig6 trig6(const float* y) { return trig6_ang(y[3], y[4], y[5]); }
+// attitude of a state in error coordinates (z[3..5] = setPoint - angle)
+template <class SP>
+__device__ __forceinline__ Trig6 trig6_err(const SP& sps, const float* z) {
+    float sp[6];
+    sps.get(sp);
+    return trig6_ang(sp[3] - z[3], sp[4] - z[4], sp[5] - z[5]);
+}
+
+// Register parking (fp32 FAITHFUL step kernels, MVRL_PARK): the sub-step's base state y[12] and the RK4 slope accumulator
+// acc[12] are needed only between the stages, not inside an RHS evaluation - they wait in LDS (a wave-private 6 KB
+// tile, 3 x 16 B per lane and array, conflict-free b128 accesses, no barrier: a lane only reads what it wrote) so that
+// the RHS has 24 more registers.  That takes the kernel from 156 to <= 128 VGPRs = FOUR resident waves per SIMD instead
+// of three; the SIMD's issue slots rotate over 1, 2, 4 or 8 wave slots, so a fourth wave is worth more than a third
+// (tools/valu_dep.hip, DESIGN.md section 5).  33 LDS instructions per sub-step against ~1450 VALU.
+#if !MVRL_F64 && !defined(MVRL_NO_PARK)
+#define MVRL_PARK_ON 1
+#ifdef MVRL_JIT_MIN_WAVES   /* mvrl_specialize: literal constants need no SGPR headroom; the dense form is tried at 4 waves first */
+#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, MVRL_JIT_MIN_WAVES)
+#else
+#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, SYM ? 4 : 2)
+#endif
+// LDS per block = 10 KB although the parked tiles need 6: 160 KB / 10 KB = 16 one-wave blocks per CU = exactly four waves
+// per SIMD.  A kernel instance that happens to need <= 96 VGPRs would otherwise get a FIFTH wave, and five waves rotate
+// over eight issue slots (tools/valu_dep.hip).
+#ifndef MVRL_PARK_FLOAT4S
+#define MVRL_PARK_FLOAT4S 640
+#endif
+struct Park12 {
+    volatile float4* base;   // [3][MVRL_STEP_BLOCK]
+    __device__ __forceinline__ void put(const float* v) const {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float4 t; t.x = v[4 * j]; t.y = v[4 * j + 1]; t.z = v[4 * j + 2]; t.w = v[4 * j + 3];
+            const_cast<float4&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]) = t;
+        }
+        asm volatile("" ::: "memory");   // no store-to-load forwarding across the parking: the value must leave its registers
+    }
+    __device__ __forceinline__ void get(float* v) const {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float4 t = const_cast<const float4&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]);
+            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        }
+    }
+};
+// The set-point of the step: needed inside the RK4 loop only by lanes that take a full sincos (stage_trig) and after it (pose
+// = set-point - error, observation) - six registers the right-hand side can use instead.
+struct SpStore {
+    volatile float4* base;   // [2][MVRL_STEP_BLOCK]
+    __device__ __forceinline__ void put(const float* sp) const {
+        float4 a, b; a.x = sp[0]; a.y = sp[1]; a.z = sp[2]; a.w = sp[3]; b.x = sp[4]; b.y = sp[5]; b.z = 0.f; b.w = 0.f;
+        const_cast<float4&>(base[threadIdx.x]) = a;
+        const_cast<float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]) = b;
+        asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ void get(float* sp) const {
+        asm volatile("" ::: "memory");
+        const float4 a = const_cast<const float4&>(base[threadIdx.x]), b = const_cast<const float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]);
+        sp[0] = a.x; sp[1] = a.y; sp[2] = a.z; sp[3] = a.w; sp[4] = b.x; sp[5] = b.y;
+    }
+};
+#else
+#define MVRL_STEP_BOUNDS6 MVRL_STEP_BOUNDS
+struct SpStore {   // no parking (fp64 build, MVRL_NO_PARK): the set-point stays in registers
+    float v[6];
+    __device__ __forceinline__ void put(const float* sp) { for (int q = 0; q < 6; q++) v[q] = sp[q]; }
+    __device__ __forceinline__ void get(float* sp) const { for (int q = 0; q < 6; q++) sp[q] = v[q]; }
+};
+#endif
+
 
 // sin/cos of the attitude at an RK stage whose angles differ from known ones (the sub-step's base attitude) by the small,
 // known increments d[3..5] (= c * k of the previous stage): rotate the base values by (cos d, sin d) from short Taylor
@@ -308,13 +393,17 @@ __device__ __forceinline__ Trig6 trig6(const float* y) {
 // stages of every sub-step, and the base attitude of every sub-step after the first (rotated by the sub-step's own
 // increment).  |d| <= 0.25 is checked per lane (truncation: 1.2e-8 in sin d, 4e-10 in cos d; the vehicle turns at < 3 rad/s,
 // d = h * rate < 0.15); a lane with a larger increment, and the fp64 build (whose parity bar is 1e-9), evaluate in full.
-__device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, const float* d) {
+struct NoSp { __device__ __forceinline__ void get(float* sp) const { for (int q = 0; q < 6; q++) sp[q] = 0.f; } };
+template <bool ERRC = false, class SP = NoSp>
+__device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, const float* d, const SP& sp = SP()) {
+    // ERRC: yt is in error coordinates (the FAITHFUL / ZOH loops of the step kernel): absolute angles = set-point - yt
+#define MVRL_FULL_TRIG() (ERRC ? trig6_err(sp, yt) : trig6(yt))
 #if MVRL_F64 || defined(MVRL_FULL_STAGE_TRIG)
-    return trig6(yt);
+    return MVRL_FULL_TRIG();
 #else
     const float m = fmaxf(fmaxf(fabsf(d[3]), fabsf(d[4])), fabsf(d[5]));
 #ifdef MVRL_TRIG_WAVE_FALLBACK
-    if (__builtin_expect(__any(m > 0.25f), 0)) return trig6(yt);   // the whole wave evaluates the stage in full
+    if (__builtin_expect(__any(m > 0.25f), 0)) return MVRL_FULL_TRIG();   // the whole wave evaluates the stage in full
 #endif
     Trig6 t;
     float sd[3], cd[3];
@@ -334,10 +423,11 @@ __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, con
     // take the full evaluation as a DIVERGENT branch: the wave issues those ~80 instructions with one or two lanes enabled.
     // The chip runs this kernel at its power limit, where an instruction's cost is the lanes it
     // switches, not its issue slot - cheaper than sending all 64 lanes through the full evaluation whenever one needs it.
-    if (m > 0.25f) t = trig6(yt);
+    if (m > 0.25f) t = MVRL_FULL_TRIG();
 #endif
     return t;
 #endif
+#undef MVRL_FULL_TRIG
 }
 
 // One RHS evaluation in FAITHFUL mode = BlueROV2Heavy6DoF.derivs (6DoF.py:406-442), PID state mutated.
@@ -351,12 +441,13 @@ __device__ __forceinline__ void write_aux6(PP p, const float* u, const float* cv
 }
 
 template <bool SYM, bool FLOW, bool HAS_DT, bool USE_INC, class PP>
-__device__ __forceinline__ void derivs6(PP p, const float* y, const Trig6& t, const float* sp, Pid6& pid, float half_dtp,
+__device__ __forceinline__ void derivs6(PP p, const float* y, const Trig6& t, Pid6& pid, float half_dtp,
                                         const float* kd_inv, const float* dpose, bool inc_valid, float2 cur, float* dy,
-                                        float* aux_row) {
+                                        float* aux_row, bool fixed, const SpStore& e0s) {
+    // y: [error coordinates of the pose (6) | body velocities (6)]
     Axes ax = body_axes(t);
     float u[6], F[8], cv[8];
-    pid6<HAS_DT, USE_INC>(p, y, sp, pid, half_dtp, kd_inv, dpose, inc_valid, u);
+    pid6<HAS_DT, USE_INC>(p, y, pid, half_dtp, kd_inv, dpose, inc_valid, u, fixed, e0s);
     allocate6<SYM>(p, ax, u, F, cv);
     if (aux_row) write_aux6(p, u, cv, aux_row);  // wave-uniform: last RHS call of the step, aux enabled
     dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, dy);
@@ -463,53 +554,13 @@ __device__ unsigned long long g_stamp_rt[5 * MVRL_STAMP_WAVES];   // s_memrealti
 #define STAMP(slot) do {} while (0)
 #endif
 
-// Register parking (fp32 FAITHFUL step kernels, MVRL_PARK): the sub-step's base state y[12] and the RK4 slope accumulator
-// acc[12] are needed only between the stages, not inside an RHS evaluation - they wait in LDS (a wave-private 6 KB
-// tile, 3 x 16 B per lane and array, conflict-free b128 accesses, no barrier: a lane only reads what it wrote) so that
-// the RHS has 24 more registers.  That takes the kernel from 156 to <= 128 VGPRs = FOUR resident waves per SIMD instead
-// of three; the SIMD's issue slots rotate over 1, 2, 4 or 8 wave slots, so a fourth wave is worth more than a third
-// (tools/valu_dep.hip, DESIGN.md section 5).  33 LDS instructions per sub-step against ~1450 VALU.
-#if !MVRL_F64 && !defined(MVRL_NO_PARK)
-#define MVRL_PARK_ON 1
-#ifdef MVRL_JIT_MIN_WAVES   /* mvrl_specialize: literal constants need no SGPR headroom; the dense form is tried at 4 waves first */
-#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, MVRL_JIT_MIN_WAVES)
-#else
-#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, SYM ? 4 : 2)
-#endif
-// LDS per block = 10 KB although the parked tiles need 6: 160 KB / 10 KB = 16 one-wave blocks per CU = exactly four waves
-// per SIMD.  A kernel instance that happens to need <= 96 VGPRs would otherwise get a FIFTH wave, and five waves rotate
-// over eight issue slots (tools/valu_dep.hip).
-#ifndef MVRL_PARK_FLOAT4S
-#define MVRL_PARK_FLOAT4S 640
-#endif
-struct Park12 {
-    volatile float4* base;   // [3][MVRL_STEP_BLOCK]
-    __device__ __forceinline__ void put(const float* v) const {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            float4 t; t.x = v[4 * j]; t.y = v[4 * j + 1]; t.z = v[4 * j + 2]; t.w = v[4 * j + 3];
-            const_cast<float4&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]) = t;
-        }
-        asm volatile("" ::: "memory");   // no store-to-load forwarding across the parking: the value must leave its registers
-    }
-    __device__ __forceinline__ void get(float* v) const {
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const float4 t = const_cast<const float4&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]);
-            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
-        }
-    }
-};
-#else
-#define MVRL_STEP_BOUNDS6 MVRL_STEP_BOUNDS
-#endif
-
 // MULTI: io.k_steps consecutive env steps in ONE launch (mvrl_rollout_dev): the same body run k_steps times on
 // actions[k] -> obs[k] / reward[k] / done[k], k = 0 .. k_steps-1.  A lane only ever touches its own planes, so no
 // synchronisation is needed between the steps; what the fused launch saves is the ~6 us between dependent launches, the
 // ramp and tail of every launch, and the HBM latency of the state loads (the lane's planes come back from L2).
-template <class PP, bool SYM, bool ZOH, bool FLOW, int INTEG, bool MULTI = false>
+// FIXED: fixed set-point mode (mvrl_config.fixed_setpoint; 6DoF.py:536-541) - a compile-time flavour so that the action mode
+// carries neither its registers nor its branches.
+template <class PP, bool SYM, bool ZOH, bool FLOW, int INTEG, bool MULTI = false, bool FIXED = false>
 __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ pg, const StepIO io, const FlowDev fl) {
     const PP p = param_ptr<PP>(pg);
     const uint32_t i_in = (uint32_t)io.lane0 + blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
@@ -519,6 +570,10 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     __shared__ float4 park_lds[MVRL_PARK_FLOAT4S];
     static_assert(MVRL_PARK_FLOAT4S >= 2 * 3 * MVRL_STEP_BLOCK, "parking tile");
     const Park12 park_y{park_lds}, park_a{park_lds + 3 * MVRL_STEP_BLOCK};
+    static_assert(MVRL_PARK_FLOAT4S >= 10 * MVRL_STEP_BLOCK, "parking tile + origin store + start-of-step error");
+    SpStore sps{park_lds + 6 * MVRL_STEP_BLOCK}, e0s{park_lds + 8 * MVRL_STEP_BLOCK};
+#else
+    SpStore sps, e0s;
 #endif
     // the env's state: loaded before the first step of a launch and stored after the last one - in a fused launch it
     // stays in registers in between
@@ -563,21 +618,42 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     // on the bulk of the state): fixed set-point -> the stored planes (6DoF.py:536-541), else the action row
     float spin[6];
     {
-        const float* arow = io.fixed_sp ? nullptr : actions_k + (size_t)i_in * 6;
+        const float* arow = FIXED ? nullptr : actions_k + (size_t)i_in * 6;
 #pragma unroll
-        for (int k = 0; k < 6; k++) spin[k] = io.fixed_sp ? ST(R6_SP + k) : arow[k];
+        for (int k = 0; k < 6; k++) spin[k] = FIXED ? ST(R6_SP + k) : arow[k];
     }
     const bool first = (istep == 0);  // controller.eOld is None until the first call (6DoF.py:62-63)
     istep += 1;                       // 6DoF.py:533
     FlowTap tap;
     if (FLOW)  // sampled once per env step at the pre-step position, time AFTER the increment
         tap = flow_gather(fl, (float)istep * io.dt + toff, y[0], y[1]);
+    // ERROR COORDINATES.  The set-point is constant inside an env step and the pose enters the right-hand side only through
+    // the controller's error e = setPoint - pose (and through sines and cosines, which are carried by rotation, stage_trig).
+    // The RK4 loop below therefore integrates z = setPoint - pose instead of the pose: dz/dt = -J nu.  In the reference's
+    // action mode setPoint = a * scale + pose (6DoF.py:545-552), so z starts the step at a * scale - at most 0.9 m / 0.79 rad,
+    // resolved eight times finer in fp32 than a pose of several metres, and the PID reads it without the subtraction
+    // sp - y at every call (-5 instructions per call).  The pose is put together again once, after the last sub-step.
+    // With a FIXED set-point (6DoF.py:536-541) the error is not small; the integrated variable is then the displacement since
+    // the start of the step, z = pose_start - pose (it starts at 0), and the controller adds E0 = setPoint - pose_start, which
+    // waits in LDS (pid6).  Either way pose = origin - z with origin = setPoint (action mode) or pose_start (fixed mode).
+    constexpr bool fixed = FIXED;
+    float z0[6], org[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++)  // 6DoF.py:545-552
-        sp[k] = io.fixed_sp ? spin[k] : fmaf(spin[k], p->act_scale[k], y[k]);
+    for (int k = 0; k < 6; k++) {  // 6DoF.py:545-552
+        const float da = spin[k] * p->act_scale[k];
+        sp[k] = fixed ? spin[k] : da + y[k];
+        z0[k] = fixed ? spin[k] - y[k] : da;          // the error at the start of the step (yaw: unwrapped)
+        org[k] = fixed ? y[k] : sp[k];
+    }
     if (first) {
-        pid.eold[0] = sp[0] - y[0]; pid.eold[1] = sp[1] - y[1]; pid.eold[2] = sp[2] - y[2];
-        pid.eold[3] = sp[3] - y[3]; pid.eold[4] = sp[4] - y[4]; pid.eold[5] = angle_error(sp[5], y[5]);
+#pragma unroll
+        for (int k = 0; k < 5; k++) pid.eold[k] = z0[k];
+        pid.eold[5] = angle_error(z0[5], 0.f);
+    }
+    if (fixed) {
+        e0s.put(z0);
+#pragma unroll
+        for (int k = 0; k < 6; k++) z0[k] = 0.f;
     }
 
     const float h_s = io.dt / (float)io.n_sub;
@@ -598,7 +674,6 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     // pose increment between the last PID call of a sub-step and the first of the next; not known across env steps
     // (new set-point, angle wrap): the first call of a step uses the rounded difference (inc_valid = false)
     float inc_prev[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    Trig6 tb = {0.f, 1.f, 0.f, 1.f, 0.f, 1.f};   // FAITHFUL: base attitude of the current sub-step
 #ifdef MVRL_STAMP_ON
     {   // everything the loop needs has arrived
         float dep = y[0] + y[11] + pid.eint[5] + pid.eold[5] + sp[5] + cur.x;
@@ -620,18 +695,24 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
         if (io.nfev) io.nfev[i_in] = nfev;
     } else
 #endif
+    {
+    sps.put(org);
+    Trig6 tb = trig6(y);   // attitude at the start of the step: the one full sincos of the step (FAITHFUL: base of the first sub-step)
+#pragma unroll
+    for (int q = 0; q < 6; q++) y[q] = z0[q];          // from here to the end of the loop y[0..5] is the ERROR setPoint - pose
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[12], acc[12], yt[12];
         float tb_inc[3] = {0.f, 0.f, 0.f};
         float* const aux_last = (ks == io.n_sub - 1) ? aux_row : nullptr;
         if (ZOH) {
             // PID + allocation once per sub-step; t - tOld = h except for the very first call after reset (= 0)
-            Trig6 t = trig6(y);
+            Trig6 t = tb;
+            if (ks > 0) t = trig6_err(sps, y);
             Axes ax = body_axes(t);
             float u[6], F[8];
             const bool very_first = first && (ks == 0);
-            if (very_first) pid6<false, false>(p, y, sp, pid, 0.f, nullptr, nullptr, false, u);
-            else pid6<true, true>(p, y, sp, pid, half_dtp, kd_inv, inc_prev, ks > 0, u);
+            if (very_first) pid6<false, false>(p, y, pid, 0.f, nullptr, nullptr, false, u, fixed, e0s);
+            else pid6<true, true>(p, y, pid, half_dtp, kd_inv, inc_prev, ks > 0, u, fixed, e0s);
             float cvz[8];
             allocate6<SYM>(p, ax, u, F, cvz);
             if (aux_last) write_aux6(p, u, cvz, aux_last);
@@ -643,54 +724,54 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_y.put(y);
                 park_a.put(k);
 #pragma unroll
-                for (int q = 0; q < 12; q++) yt[q] = fmaf(hh, k[q], y[q]);
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]);
 #pragma unroll
                 for (int q = 3; q < 6; q++) dz[q] = hh * k[q];
-                dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
+                dynamics_only6<SYM, FLOW>(p, yt, stage_trig<true>(t, yt, dz, sps), F, cur, k);
                 park_a.get(a);
 #pragma unroll
                 for (int q = 0; q < 12; q++) a[q] = fmaf(2.f, k[q], a[q]);
                 park_a.put(a);
                 park_y.get(yb);
 #pragma unroll
-                for (int q = 0; q < 12; q++) yt[q] = fmaf(hh, k[q], yb[q]);
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], yb[q]);
 #pragma unroll
                 for (int q = 3; q < 6; q++) dz[q] = hh * k[q];
-                dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
+                dynamics_only6<SYM, FLOW>(p, yt, stage_trig<true>(t, yt, dz, sps), F, cur, k);
                 park_a.get(a);
 #pragma unroll
                 for (int q = 0; q < 12; q++) a[q] = fmaf(2.f, k[q], a[q]);
                 park_a.put(a);
                 park_y.get(yb);
 #pragma unroll
-                for (int q = 0; q < 12; q++) yt[q] = fmaf(h, k[q], yb[q]);
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -h : h, k[q], yb[q]);
 #pragma unroll
                 for (int q = 3; q < 6; q++) dz[q] = h * k[q];
-                dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
+                dynamics_only6<SYM, FLOW>(p, yt, stage_trig<true>(t, yt, dz, sps), F, cur, k);
                 park_a.get(a);
                 park_y.get(yb);
 #pragma unroll
                 for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (a[q] + k[q]);
 #pragma unroll
-                for (int q = 0; q < 12; q++) y[q] = fmaf(h6, a[q] + k[q], yb[q]);
+                for (int q = 0; q < 12; q++) y[q] = fmaf(q < 6 ? -h6 : h6, a[q] + k[q], yb[q]);
                 continue;
             }
 #endif
 #pragma unroll
-            for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
+            for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]); }
 #pragma unroll
             for (int q = 3; q < 6; q++) dz[q] = hh * k[q];
-            dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
+            dynamics_only6<SYM, FLOW>(p, yt, stage_trig<true>(t, yt, dz, sps), F, cur, k);
 #pragma unroll
-            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
+            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]); }
 #pragma unroll
             for (int q = 3; q < 6; q++) dz[q] = hh * k[q];
-            dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
+            dynamics_only6<SYM, FLOW>(p, yt, stage_trig<true>(t, yt, dz, sps), F, cur, k);
 #pragma unroll
-            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
+            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(q < 6 ? -h : h, k[q], y[q]); }
 #pragma unroll
             for (int q = 3; q < 6; q++) dz[q] = h * k[q];
-            dynamics_only6<SYM, FLOW>(p, yt, stage_trig(t, yt, dz), F, cur, k);
+            dynamics_only6<SYM, FLOW>(p, yt, stage_trig<true>(t, yt, dz, sps), F, cur, k);
 #pragma unroll
             for (int q = 0; q < 6; q++) inc_prev[q] = h6 * (acc[q] + k[q]);  // pose change over this sub-step
         } else {
@@ -701,18 +782,18 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             for (int q = 0; q < 6; q++) dp[q] = inc_prev[q];
             // the sub-step's base attitude: the three later stages rotate it (stage_trig), and so does the next sub-step
             // (re-anchored by a full evaluation at the first sub-step of an env step and every fourth one after it)
-            if ((ks & 3) == 0) tb = trig6(y);
+            if (ks > 0 && (ks & 3) == 0) tb = trig6_err(sps, y);   // re-anchored every fourth sub-step (n_sub > 4 only)
 #ifdef MVRL_PARK_ON
             {
                 // same arithmetic, same order of operations as below; y and acc live in LDS between the stages
                 park_y.put(y);
-                derivs6<SYM, FLOW, false, true>(p, y, tb, sp, pid, 0.f, nullptr, dp, ks > 0, cur, k, nullptr);
+                derivs6<SYM, FLOW, false, true>(p, y, tb, pid, 0.f, nullptr, dp, ks > 0, cur, k, nullptr, fixed, e0s);
                 park_a.put(k);
 #pragma unroll
-                for (int q = 0; q < 12; q++) yt[q] = fmaf(hh, k[q], y[q]);
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]);
 #pragma unroll
                 for (int q = 0; q < 6; q++) dp[q] = hh * k[q];
-                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, dp), sp, pid, half_dtp, kd_inv, dp, true, cur, k, nullptr);
+                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig<true>(tb, yt, dp, sps), pid, half_dtp, kd_inv, dp, true, cur, k, nullptr, fixed, e0s);
                 float d2[6], d3[6], a[12], yb[12];
                 park_a.get(a);
 #pragma unroll
@@ -722,8 +803,8 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_a.put(a);
                 park_y.get(yb);
 #pragma unroll
-                for (int q = 0; q < 12; q++) yt[q] = fmaf(hh, k[q], yb[q]);
-                derivs6<SYM, FLOW, false, true>(p, yt, stage_trig(tb, yt, d2), sp, pid, 0.f, nullptr, dp, true, cur, k, nullptr);
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], yb[q]);
+                derivs6<SYM, FLOW, false, true>(p, yt, stage_trig<true>(tb, yt, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, nullptr, fixed, e0s);
 #pragma unroll
                 for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
                 park_a.get(a);
@@ -732,46 +813,54 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_a.put(a);
                 park_y.get(yb);
 #pragma unroll
-                for (int q = 0; q < 12; q++) yt[q] = fmaf(h, k[q], yb[q]);
-                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, d3), sp, pid, half_dtp, kd_inv, dp, true, cur, k, aux_last);
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -h : h, k[q], yb[q]);
+                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig<true>(tb, yt, d3, sps), pid, half_dtp, kd_inv, dp, true, cur, k, aux_last, fixed, e0s);
                 park_a.get(a);
                 park_y.get(yb);
 #pragma unroll
                 for (int q = 0; q < 6; q++) { d2[q] = h6 * (a[q] + k[q]); inc_prev[q] = d2[q] - d3[q]; }
 #pragma unroll
-                for (int q = 0; q < 12; q++) y[q] = fmaf(h6, a[q] + k[q], yb[q]);
-                if (((ks + 1) & 3) != 0 && ks + 1 < io.n_sub) tb = stage_trig(tb, y, d2);
+                for (int q = 0; q < 12; q++) y[q] = fmaf(q < 6 ? -h6 : h6, a[q] + k[q], yb[q]);
+                if (((ks + 1) & 3) != 0 && ks + 1 < io.n_sub) tb = stage_trig<true>(tb, y, d2, sps);
                 continue;
             }
 #endif
-            derivs6<SYM, FLOW, false, true>(p, y, tb, sp, pid, 0.f, nullptr, dp, ks > 0, cur, k, nullptr);
+            derivs6<SYM, FLOW, false, true>(p, y, tb, pid, 0.f, nullptr, dp, ks > 0, cur, k, nullptr, fixed, e0s);
 #pragma unroll
-            for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(hh, k[q], y[q]); }
+            for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]); }
 #pragma unroll
             for (int q = 0; q < 6; q++) dp[q] = hh * k[q];                       // (y + hh k1) - y
-            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, dp), sp, pid, half_dtp, kd_inv, dp, true, cur, k, nullptr);
+            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig<true>(tb, yt, dp, sps), pid, half_dtp, kd_inv, dp, true, cur, k, nullptr, fixed, e0s);
             float d2[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }  // hh (k2 - k1)
 #pragma unroll
-            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(hh, k[q], y[q]); }
-            derivs6<SYM, FLOW, false, true>(p, yt, stage_trig(tb, yt, d2), sp, pid, 0.f, nullptr, dp, true, cur, k, nullptr);
+            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]); }
+            derivs6<SYM, FLOW, false, true>(p, yt, stage_trig<true>(tb, yt, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, nullptr, fixed, e0s);
             float d3[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }          // h k3 - hh k2
 #pragma unroll
-            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(h, k[q], y[q]); }
-            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig(tb, yt, d3), sp, pid, half_dtp, kd_inv, dp, true, cur, k, aux_last);
+            for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(q < 6 ? -h : h, k[q], y[q]); }
+            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig<true>(tb, yt, d3, sps), pid, half_dtp, kd_inv, dp, true, cur, k, aux_last, fixed, e0s);
 #pragma unroll
             for (int q = 0; q < 6; q++) { d2[q] = h6 * (acc[q] + k[q]); inc_prev[q] = d2[q] - d3[q]; }   // y_new - (y + h k3)
             tb_inc[0] = d2[3]; tb_inc[1] = d2[4]; tb_inc[2] = d2[5];
         }
 #pragma unroll
-        for (int q = 0; q < 12; q++) y[q] = fmaf(h6, acc[q] + k[q], y[q]);
+        for (int q = 0; q < 12; q++) y[q] = fmaf(q < 6 ? -h6 : h6, acc[q] + k[q], y[q]);
         if (!ZOH && ((ks + 1) & 3) != 0 && ks + 1 < io.n_sub) {
             const float dd[6] = {0.f, 0.f, 0.f, tb_inc[0], tb_inc[1], tb_inc[2]};
-            tb = stage_trig(tb, y, dd);
+            tb = stage_trig<true>(tb, y, dd, sps);
         }
+    }
+    sps.get(org);
+#pragma unroll
+    for (int q = 0; q < 6; q++) y[q] = org[q] - y[q];   // back to the pose
+    if (!fixed) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) sp[q] = org[q];
+    }
     }
 #ifdef MVRL_STAMP_ON
     asm volatile("" : "+v"(y[0]), "+v"(y[11]));
@@ -789,6 +878,10 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
 
 #pragma unroll
     for (int k = 0; k < 6; k++) path[k] = ST(R6_PATH + k);  // only the observation needs the way-points
+    if (fixed) {   // the set-point itself did not ride through the loop (origin = pose_start there)
+#pragma unroll
+        for (int k = 0; k < 6; k++) sp[k] = ST(R6_SP + k);
+    }
     float o[9];
     observe6(p, y, path, sp, o);
     const bool done = istep >= io.max_steps;  // 6DoF.py:569-571
@@ -805,7 +898,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
         float ang[3];
         const int episode = unpack_int(ST(R6_EPISODE)) + 1;
         ST(R6_EPISODE) = pack_int(episode);
-        if (io.fixed_sp) {
+        if (FIXED) {
             // reset(initialSetpoint=sp) keeps the set-point: path/sp stay (6DoF.py:500-511), and so does the time offset
 #pragma unroll
             for (int q = 0; q < 3; q++) { ang[q] = sp[3 + q]; }
@@ -830,7 +923,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
         for (int k = 0; k < 12; k++) ST(R6_Y + k) = y[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) { ST(R6_EOLD + k) = pid.eold[k]; ST(R6_EINT + k) = pid.eint[k]; }
-        if (!io.fixed_sp) {
+        if (!FIXED) {
 #pragma unroll
             for (int k = 0; k < 6; k++) ST(R6_SP + k) = sp[k];
         }
@@ -847,8 +940,11 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
 #ifdef MVRL_JIT
 // The two instances mvrl_specialize loads, by explicit instantiation: hiprtc's name-expression mechanism would add a
 // writable table of kernel addresses to the code object (its only global variable).
-template __global__ void rov6_step_kernel<const Rov6Baked*, MVRL_JIT_SYM, MVRL_JIT_ZOH, false, 0, true>(const Rov6Dev*, const StepIO, const FlowDev);
-template __global__ void rov6_step_kernel<const Rov6Baked*, MVRL_JIT_SYM, MVRL_JIT_ZOH, true, 0, true>(const Rov6Dev*, const StepIO, const FlowDev);
+#ifndef MVRL_JIT_FIXED
+#define MVRL_JIT_FIXED false
+#endif
+template __global__ void rov6_step_kernel<const Rov6Baked*, MVRL_JIT_SYM, MVRL_JIT_ZOH, false, 0, true, MVRL_JIT_FIXED>(const Rov6Dev*, const StepIO, const FlowDev);
+template __global__ void rov6_step_kernel<const Rov6Baked*, MVRL_JIT_SYM, MVRL_JIT_ZOH, true, 0, true, MVRL_JIT_FIXED>(const Rov6Dev*, const StepIO, const FlowDev);
 #endif
 #ifndef MVRL_JIT   /* everything below is built ahead of time only */
 #ifdef MVRL_STAMP_ON
@@ -1070,14 +1166,18 @@ hipError_t launch_rov6_derivs(const Rov6Dev* p, bool baked, bool sym, int64_t n,
 hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& fl, bool baked, bool ctrl, bool sym, bool zoh,
                             bool flow, bool rk45, hipStream_t stream) {
     dim3 grid((unsigned)((io.lane_end - io.lane0 + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
-#define MVRL_L6(S, Z, F) hipLaunchKernelGGL((rov6_step_kernel<CP6, S, Z, F, 0>), grid, block, 0, stream, p, io, fl)
-#define MVRL_L6B(Z, F) hipLaunchKernelGGL((rov6_step_kernel<const Rov6Baked*, true, Z, F, 0>), grid, block, 0, stream, p, io, fl)
+    // every flavour exists for the action mode and for the fixed set-point mode (template flag FIXED)
+#define MVRL_GO6(PPT, S, Z, F, I, M)                                                                                              \
+    do {                                                                                                                         \
+        if (io.fixed_sp) hipLaunchKernelGGL((rov6_step_kernel<PPT, S, Z, F, I, M, true>), grid, block, 0, stream, p, io, fl);    \
+        else hipLaunchKernelGGL((rov6_step_kernel<PPT, S, Z, F, I, M, false>), grid, block, 0, stream, p, io, fl);               \
+    } while (0)
+#define MVRL_L6(S, Z, F) MVRL_GO6(CP6, S, Z, F, 0, false)
+#define MVRL_L6B(Z, F) MVRL_GO6(const Rov6Baked*, true, Z, F, 0, false)
 #if MVRL_F64
     if (rk45) {  // adaptive integrator: run-time constants, generic or sym arithmetic, FAITHFUL placement by definition
-        if (sym) { if (flow) hipLaunchKernelGGL((rov6_step_kernel<CP6, true, false, true, 1>), grid, block, 0, stream, p, io, fl);
-                   else hipLaunchKernelGGL((rov6_step_kernel<CP6, true, false, false, 1>), grid, block, 0, stream, p, io, fl); }
-        else { if (flow) hipLaunchKernelGGL((rov6_step_kernel<CP6, false, false, true, 1>), grid, block, 0, stream, p, io, fl);
-               else hipLaunchKernelGGL((rov6_step_kernel<CP6, false, false, false, 1>), grid, block, 0, stream, p, io, fl); }
+        if (sym) { if (flow) MVRL_GO6(CP6, true, false, true, 1, false); else MVRL_GO6(CP6, true, false, false, 1, false); }
+        else { if (flow) MVRL_GO6(CP6, false, false, true, 1, false); else MVRL_GO6(CP6, false, false, false, 1, false); }
         return hipGetLastError();
     }
 #endif
@@ -1089,7 +1189,7 @@ hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& f
 #else
     if (io.k_steps > 1 && (baked || ctrl || sym)) {
 #endif
-#define MVRL_L6M(PPT, Z, F) hipLaunchKernelGGL((rov6_step_kernel<PPT, true, Z, F, 0, true>), grid, block, 0, stream, p, io, fl)
+#define MVRL_L6M(PPT, Z, F) MVRL_GO6(PPT, true, Z, F, 0, true)
         if (baked) {
             if (zoh) { if (flow) MVRL_L6M(const Rov6Baked*, true, true); else MVRL_L6M(const Rov6Baked*, true, false); }
             else { if (flow) MVRL_L6M(const Rov6Baked*, false, true); else MVRL_L6M(const Rov6Baked*, false, false); }
@@ -1118,6 +1218,7 @@ hipError_t launch_rov6_step(const Rov6Dev* p, const StepIO& io, const FlowDev& f
     }
 #undef MVRL_L6
 #undef MVRL_L6B
+#undef MVRL_GO6
     return hipGetLastError();
 }
 

@@ -33,6 +33,11 @@ NAMES = ["pid-increment sign", "thruster dead-band", "wind-up limit", "yaw-error
 # multiplies pose rounding by K_D / h ~ 400..800 every sub-step; the smallest jump, one thruster crossing its dead-band for
 # one stage at n_sub 8, moves a velocity by 7e-5).  Such envs are counted separately and bounded in number.
 SMOOTH_TOL = 6e-5
+# At n_sub 8 (h = 25 ms, K_D / h twice as large) the ACCEPTED drift of ordinary envs itself reaches 6-8e-5 after 12+ steps, so the
+# drift / jump line sits higher there; what that costs is stated: a genuine smallest jump (7e-5) is then counted as drift, and
+# drift is bounded in number (max_smooth_share), not excused.  The perturbation ensemble is no help at n_sub 8 (it flags 12-16 %
+# of ordinary envs; assert_explained refuses it above MAX_FALSE_EXCUSE).
+SMOOTH_TOL_NSUB8 = 1e-4
 
 
 class OutlierAudit:
@@ -40,8 +45,10 @@ class OutlierAudit:
     the step at which that first happens must have passed - in that step or the one before - within the fp32 bound of a
     discontinuity).  Envs beyond tol that never pass SMOOTH_TOL drifted (accumulated rounding) and are bounded in number."""
 
-    def __init__(self, n, tol, bounds=None, dof=6):
+    def __init__(self, n, tol, bounds=None, dof=6, smooth_tol=None):
         self.n, self.tol, self.bounds = n, tol, np.asarray(bounds_for(dof) if bounds is None else bounds, float)
+        # jump threshold of this run (module default SMOOTH_TOL; n_sub 8 passes SMOOTH_TOL_NSUB8)
+        self.smooth_tol = SMOOTH_TOL if smooth_tol is None else float(smooth_tol)
         self.first_bad = np.full(n, -1)                               # step at which the env first exceeded tol
         self.first_jump = np.full(n, -1)                              # ... first exceeded SMOOTH_TOL
         self.margin_at_jump = np.full((n, len(self.bounds)), np.inf)  # smallest distances during that step and the one before
@@ -57,7 +64,7 @@ class OutlierAudit:
         margins = np.asarray(margins, float)
         newly = (err > self.tol) & (self.first_bad < 0)
         self.first_bad[newly] = self.step_no
-        jump = (err > SMOOTH_TOL) & (self.first_jump < 0)
+        jump = (err > self.smooth_tol) & (self.first_jump < 0)
         self.first_jump[jump] = self.step_no
         self.margin_at_jump[jump] = np.minimum(margins, self.prev)[jump]
         self.err_at_jump[jump] = err[jump]
@@ -93,7 +100,7 @@ class OutlierAudit:
         bad = np.nonzero(self.bad)[0]
         ex, sm = self.explained(), self.smooth()
         lines = [f"{len(bad)} / {self.n} envs beyond {self.tol:g}: {int(ex.sum())} jumped next to a discontinuity, {int(sm.sum())} drifted (never beyond "
-                 f"{SMOOTH_TOL:g}), {int(self.unexplained().sum())} jumped unexplained; per step {100 * self.near_share_per_step():.3f} % of all envs "
+                 f"{self.smooth_tol:g}), {int(self.unexplained().sum())} jumped unexplained; per step {100 * self.near_share_per_step():.3f} % of all envs "
                  f"are within the fp32 bounds of a discontinuity; worst error among the envs within tolerance {self.worst_good:.1e}"]
         for i in bad[:60]:
             if sm[i]:
@@ -112,6 +119,17 @@ class OutlierAudit:
         reference itself, perturbed at fp32-rounding level, leaves its own unperturbed trajectory there."""
         un = np.nonzero(self.unexplained())[0]
         if len(un) and resolver is not None:
+            # How often would the resolver excuse an ORDINARY env?  Measured on this run's own envs that never left the
+            # tolerance (up to 128 of them, judged at the last step): that share is its false-excuse rate.  Where it exceeds
+            # MAX_FALSE_EXCUSE the ensemble cannot tell sensitive envs from ordinary ones (n_sub 8: the accepted drift itself
+            # approaches SMOOTH_TOL) and is NOT used: the unexplained envs then fail the test.
+            calm = np.nonzero(~self.bad)[0][:128]
+            self.false_excuse_rate = float(np.mean(resolver(calm, np.full(len(calm), self.step_no - 1)))) if len(calm) else 1.0
+            print(f"resolver: false-excuse rate {100 * self.false_excuse_rate:.1f} % on {len(calm)} ordinary envs "
+                  f"({'used' if self.false_excuse_rate <= MAX_FALSE_EXCUSE else 'REFUSED'} for {len(un)} envs beyond the distance bounds)")
+            assert self.false_excuse_rate <= MAX_FALSE_EXCUSE, (
+                f"{len(un)} envs jumped beyond the distance bounds and the perturbation ensemble excuses {100 * self.false_excuse_rate:.0f} % of "
+                "ordinary envs in this parametrisation - it is not evidence here:\n" + self.report())
             sens = np.asarray(resolver(un, self.first_jump[un]), bool)
             self.resolved = int(sens.sum())
             for i in un[sens]:
@@ -126,7 +144,12 @@ class OutlierAudit:
 # ulp); the kernels round ~6000 operations per env step on top, and the deviation they accumulate is smooth and small: median
 # 2.0e-6, 99.99 % below 5e-6 after 25 steps (tests/audit/err_quantiles.py, 1 048 576 envs).  The ensemble uses the level at which
 # its own median deviation matches that accepted typical deviation - not more.
-ENSEMBLE_NOISE = 1e-7
+# Round 3 (pose integrated in error coordinates): the GPU's accepted median deviation fell from 1.98e-6 to 1.49e-6 (1 048 576 envs x
+# 25 steps, profiles/r03_error_audit_1M.txt); the ensemble's median is 1.84e-6 at 1e-7 and 9.2e-7 at 5e-8, linear in between.
+ENSEMBLE_NOISE = 8e-8
+# The resolver is only evidence where it rarely excuses an ordinary env: 3-4 % at n_sub 2 / 4 (profiles/r02_error_audit_1M.txt), 16 %
+# at n_sub 8 (profiles/r02_error_audit_other.txt) - there it is refused (OutlierAudit.assert_explained measures the rate per run).
+MAX_FALSE_EXCUSE = 0.05
 
 
 def ensemble_sensitive(oracle_mod, dof, init, actions, lanes, until, env_kw=None, toffset=None, members=48, noise=ENSEMBLE_NOISE,

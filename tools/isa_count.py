@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static VALU count of the 6-DoF step kernel's RK4 sub-step loop from `hipcc -S` output (no GPU needed).
 
-    python tools/isa_count.py [--zoh] [--noflow] [-D...]      compiles csrc/mvrl_rov6.hip for gfx950 and prints, for the baked
+    python tools/isa_count.py [--zoh] [--noflow] [--fixed] [-D...]      compiles csrc/mvrl_rov6.hip for gfx950 and prints, for the baked
                                                             FAITHFUL+flow instance: VALU instructions in the sub-step loop on the
                                                             fast path, in the divergent blocks (full sincos of single lanes), and
                                                             outside the loop; registers, scratch.
@@ -77,12 +77,13 @@ if __name__ == "__main__":
     args = sys.argv[1:]
     zoh = "--zoh" in args
     flow = "--noflow" not in args
+    fixed = "--fixed" in args
     extra = [a for a in args if a.startswith("-D") or a.startswith("-m")]
     out = "/tmp/isa/count.s"
     os.makedirs("/tmp/isa", exist_ok=True)
     compile_s(extra, out)
     b = lambda v: "Lb1E" if v else "Lb0E"
-    sym = "_ZN4mvrl16rov6_step_kernelIPKNS_9Rov6BakedELb1E" + b(zoh) + b(flow) + "Li0ELb1EEEvPKNS_7Rov6DevENS_6StepIOENS_7FlowDevE"
+    sym = "_ZN4mvrl16rov6_step_kernelIPKNS_9Rov6BakedELb1E" + b(zoh) + b(flow) + "Li0ELb1E" + b(fixed) + "EEvPKNS_7Rov6DevENS_6StepIOENS_7FlowDevE"
     r = analyse(out, sym)
     est = 4 * r["fast"] + r["outer"]
     print(f"sub-step loop: fast path {r['fast']} VALU, divergent blocks {r['slow']}, {r['lds']} LDS; outside the loop {r['outer']} (+{r['outer_divergent']} divergent: reset); "
