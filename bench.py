@@ -95,8 +95,18 @@ def cpu_baseline(wl, flow_np, seed):
     for _ in range(steps):
         env.step(act)
     el = time.perf_counter() - t0
+    # the reference itself cannot travel to the GPU box; its own NumPy figures, measured in the build container, ride along
+    ref_np = {"rov6": {"value": 21.7, "under_rk4_harness": 250.0,
+                       "what": "BlueROV2Heavy6DoFEnv.step, random actions, 300 steps (adaptive RK45, 181 derivs per step); "
+                               "under_rk4_harness = 1 / (16 derivs x 250 us), the integrator this benchmark runs"},
+              "rov3": {"value": 6.8, "under_rk4_harness": 450.0,
+                       "what": "BlueROV2Heavy3DoFEnv.step, 1 env, 1000 random-action steps (BASELINE configs[0]; 1047 derivs per step)"},
+              "auv": {"value": 5600.0, "under_rk4_harness": None, "what": "AuvEnv.step with flow.interp, 5000 steps"}}[wl["model"]]
+    ref_np.update({"unit": "env-steps/s", "cores": 1, "hardware": "build container, Intel Xeon 2.1 GHz, numpy 2.2.6 / scipy 1.15.3",
+                   "source": "BASELINE.md section 2 (imported reference, not run on this box)"})
     return {"value": n * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} envs x {steps} steps of the same workload, fp64 C oracle with OpenMP over envs ({el:.1f} s)"}
+            "sample": f"{n} envs x {steps} steps of the same workload, fp64 C oracle with OpenMP over envs ({el:.1f} s)",
+            "reference_numpy": ref_np}
 
 
 def self_launch(n_ranks, argv=None):
@@ -332,7 +342,7 @@ def main():
     # ---- N > 1: gather overlapped with the next step on a side stream, outputs double-buffered ---------------
     gather = None
     if world > 1 and args.gather != "none" and args.precision == "f32":   # the gather message is an fp32 format
-        gather = [D.OutputGather(world * n, obs_dim, dev, mode=args.gather) for _ in range(2)]
+        gather = [D.OutputGather(world * n, obs_dim, dev, mode=args.gather, reward_plane=env.has_reward) for _ in range(2)]
         side = torch.cuda.Stream(device=dev)
         pipe = D.GatherPipeline(gather, side)
 
@@ -448,16 +458,17 @@ def main():
         achieved = wl["bytes"] * n / per_step_s / 1e9
         khash = build.source_hash()
         traffic, traffic_src, valu = None, None, None
-        tp = os.path.join(REPO, "profiles", "r02_counters.json")
+        tp = os.path.join(REPO, "profiles", "r03_counters.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                ent = tj.get("workloads", {}).get(args.workload)
+                # a workload at another batch size is profiled under <workload>_<envs> (tools/profile_round.sh ... --envs-per-gpu N)
+                ent = tj.get("workloads", {}).get(args.workload if n == wl["n"] else f"{args.workload}_{n}")
                 # counters describe ONE build of the kernels: dropped when the kernel sources have changed since
-                if ent and tj.get("kernel_source_hash") == khash and n == wl["n"] and args.precision == "f32" \
+                if ent and tj.get("kernel_source_hash") == khash and n == ent.get("envs") and args.precision == "f32" \
                         and args.control_mode == "faithful" and args.n_substeps == 4 and not args.rollout:
                     traffic = ent.get("hbm_bytes_per_step")
-                    traffic_src = {"file": "profiles/r02_counters.json", "kernel_source_hash": khash, "commit": tj.get("commit"),
+                    traffic_src = {"file": "profiles/r03_counters.json", "kernel_source_hash": khash, "commit": tj.get("commit"),
                                    # rocprofv3 --kernel-trace --stats of this command under either launch plan: a chains launch
                                    # (half the batch, two in flight) lasts about one step; a single launch IS one step
                                    "rocprof_kernel_avg_us": {"chains": ent.get("bench_command_kernel_avg_us"),
@@ -473,6 +484,15 @@ def main():
                         valu = v
             except Exception:  # noqa: BLE001
                 traffic = None
+        # what a step touches: state planes (read + written), outputs, the action batch it reads - against the 256 MB Infinity Cache
+        state_words = {"rov6": 41, "rov3": 24, "auv": 56, "auv_cyl": 56}[wl["model"]]
+        es = 8 if args.precision == "f64" else 4
+        working_set = n * (state_words * es + obs_dim * es + es + 1 + act_dim * es)
+        auv_note = ("HBM-bound kernel; working set of a step (state planes + outputs + one action batch) %.0f MB " % (working_set / 1e6) +
+                    ("FITS the 256 MB Infinity Cache: the plane traffic is served from it, above what HBM streams at - `frac` is "
+                     "then a fraction of the HBM peak but not an HBM measurement (see the %d-env run in profiles/r03_bench_table.txt)" % 4194304
+                     if working_set <= 256e6 else
+                     "exceeds the 256 MB Infinity Cache several times over: the plane traffic comes from HBM"))
         launch_desc = ("one launch per 250-step episode batch" if pd_obj is not None else
                        "mvrl_rollout_dev: %d env steps per call" % RING if roll_out is not None else
                        "hip graph of %d steps" % RING if graph is not None else
@@ -509,6 +529,7 @@ def main():
                                         "C lane-range launches under chains); FETCH_SIZE x 2 + WRITE_SIZE from separate --pmc passes",
                          "kernel_us_per_step": per_step_s * 1e6, "kernel_launches_per_step": launches / max(1e-9, steps_per_region),
                          "algorithmic_bytes_per_env_step": wl["bytes"], "valu": valu, "kernel_source_hash": khash,
+                         "working_set_MB": working_set / 1e6,
                          "single_launch": None if single is None else {
                              "kernel_us_per_launch": single, "achieved": wl["bytes"] * n / (single * 1e-6) / 1e9,
                              "frac": wl["bytes"] * n / (single * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -516,7 +537,7 @@ def main():
                                      "compare with rocprofv3's per-kernel average of the --chains 1 profile"},
                          "note": ("fused episodes: the bytes are the turbulence gathers (L2 / Infinity-Cache resident), the kernel is "
                                   "bound by instruction issue, not HBM" if pd_obj is not None else
-                                  "HBM-bound kernel" if wl["model"].startswith("auv") else
+                                  auv_note if wl["model"].startswith("auv") else
                                   "the binding roof of this kernel is VALU issue (`valu`); the HBM fraction is reported as the "
                                   "contract asks") + "; kernel_us_per_step = HIP-event time of the median K-step region / K "
                                  "(wall time on the GPU: launch gaps, ramps and tails included)"},
@@ -570,7 +591,9 @@ def main():
             out["with_gather"] = wg
             out["scaling_claim"] = ("`value` (no collective in the step: the >= 6x at 8 GPUs of the north star refers to THIS figure) and "
                                     "`with_gather.value` (BASELINE configs[4]: every step's obs/reward/done gathered to rank 0; bounded by the "
-                                    "root's xGMI ingress near 1.3e10 env-steps/s at any N, DESIGN.md 6) are both whole-job rates")
+                                    "root's xGMI ingress: %d B per env (the 6-DoF reward is identically 0 and is not sent) over at most 7 links x "
+                                    "76.8 GB/s = %.2e env-steps/s at any N, DESIGN.md 6) are both whole-job rates" % (
+                                        gather[0].msg_bytes // n, 7 * XGMI_LINK_GBS * 1e9 / (gather[0].msg_bytes / n)))
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not wl.get("loop") and wl["model"] != "auv_cyl":

@@ -44,7 +44,10 @@ class OutputGather:
     number of bytes (a requirement of dist.gather), sized for the largest shard.  `mode="all"` all-gathers instead
     (every rank ends up with the full batch - for a replicated policy)."""
 
-    def __init__(self, n_global, obs_dim, device, root=0, mode="root", group=None):
+    def __init__(self, n_global, obs_dim, device, root=0, mode="root", group=None, reward_plane=True):
+        """reward_plane=False: the rigid-body environments' reward is identically 0 (6DoF.py:575, 3DoF.py:495), so their message
+        carries no reward plane - obs | done, 37 B instead of 41 B per 6-DoF env on the link that bounds the gather; the
+        producer's reward output goes to a scratch tensor and the receiver hands out zeros."""
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.root, self.mode, self.group = root, mode, group
@@ -53,10 +56,14 @@ class OutputGather:
         self.cmax = max(c for _, c in self.ranges)
         self.count = self.ranges[self.rank][1]
         self.device = device
+        self.reward_plane = bool(reward_plane)
         self.off_rew = self.cmax * self.obs_dim * 4
-        self.off_done = self.off_rew + self.cmax * 4
+        self.off_done = self.off_rew + (self.cmax * 4 if self.reward_plane else 0)
         self.msg_bytes = (self.off_done + self.cmax + 15) // 16 * 16
         self.send = torch.zeros((self.msg_bytes,), dtype=torch.uint8, device=device)
+        # without a reward plane: where the step kernel's (all-zero) reward output lands, and what receivers see
+        self._rew_scratch = None if self.reward_plane else torch.zeros((self.cmax,), dtype=torch.float32, device=device)
+        self._rew_zero = None if self.reward_plane else torch.zeros((self.cmax,), dtype=torch.float32, device=device)
         need_recv = (mode == "all") or (self.rank == root)
         self.recv = torch.zeros((self.world, self.msg_bytes), dtype=torch.uint8, device=device) if need_recv else None
 
@@ -64,22 +71,26 @@ class OutputGather:
         """Bytes arriving at the root (or at every rank in mode "all") per env step of the global batch."""
         return self.world * self.msg_bytes
 
-    def _views(self, buf, c):
+    def _views(self, buf, c, sending=False):
         obs = buf[: self.off_rew].view(torch.float32).view(self.cmax, self.obs_dim)[:c]
-        rew = buf[self.off_rew: self.off_done].view(torch.float32)[:c]
+        if self.reward_plane:
+            rew = buf[self.off_rew: self.off_done].view(torch.float32)[:c]
+        else:
+            rew = (self._rew_scratch if sending else self._rew_zero)[:c]
         done = buf[self.off_done: self.off_done + self.cmax][:c]
         return obs, rew, done
 
     def out_views(self):
         """(obs[c, obs_dim] f32, reward[c] f32, done[c] u8): contiguous views INTO the send message for this rank's
         shard.  A producer that writes them (the step kernel) makes `pack` unnecessary."""
-        return self._views(self.send, self.count)
+        return self._views(self.send, self.count, sending=True)
 
     def pack(self, obs, reward, done):
         """Copy path for producers that own their output buffers."""
-        o, r, d = self._views(self.send, obs.shape[0])
+        o, r, d = self._views(self.send, obs.shape[0], sending=True)
         o.copy_(obs)
-        r.copy_(reward)
+        if self.reward_plane:
+            r.copy_(reward)
         d.copy_(done)
         return self.send
 
@@ -283,12 +294,17 @@ class ShardedVecEnv:
     `step_tensors(actions) -> (obs, reward, done)` returning torch tensors on `device` (MarineVecEnv on a GPU;
     tests inject a CPU stepper).  `step(actions_local)` steps the local shard and gathers the outputs."""
 
-    def __init__(self, make_shard, n_global, obs_dim, device, gather="root", group=None, scatter_act_dim=None):
+    def __init__(self, make_shard, n_global, obs_dim, device, gather="root", group=None, scatter_act_dim=None, reward_plane=None):
+        """reward_plane: whether the gather message carries rewards; None = ask the shard (`has_reward`, False for the rigid-body
+        models whose reward is identically 0), default True."""
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.offset, self.count = shard_range(n_global, self.rank, self.world)
         self.local = make_shard(self.offset, self.count, self.rank)
-        self.gather = None if gather in (None, "none") else OutputGather(n_global, obs_dim, device, mode=gather, group=group)
+        if reward_plane is None:
+            reward_plane = bool(getattr(self.local, "has_reward", True))
+        self.gather = None if gather in (None, "none") else OutputGather(n_global, obs_dim, device, mode=gather, group=group,
+                                                                         reward_plane=reward_plane)
         # scatter_act_dim = act_dim: step_global() takes the FULL action batch on rank 0 and scatters it (C2)
         self.scatter = None if scatter_act_dim is None else ActionScatter(n_global, scatter_act_dim, device, group=group)
 

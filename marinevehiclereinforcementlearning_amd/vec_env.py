@@ -112,6 +112,7 @@ class MarineVecEnv:
             except _lib.MvrlError as e:   # no compiler on this machine: the ahead-of-time kernel keeps running
                 import warnings
                 warnings.warn(f"mvrl_specialize failed, keeping the run-time-constant kernel ({self._h.variant}): {e}")
+        self.has_reward = self.model == P.MODEL_AUV      # the rigid-body environments return reward = 0. (6DoF.py:575, 3DoF.py:495)
         self.jit = self._h.jit_info()     # compiler / registers / spills of a run-time compiled kernel ("none": ahead of time)
         if self.jit["specialized"] and (self.jit["scratch_bytes"] > 0 or self.jit["sgpr_spills"] > 0 or self.jit["vgpr_spills"] > 0):
             import warnings

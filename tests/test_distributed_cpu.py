@@ -24,6 +24,8 @@ def free_port():
 class OracleShard:
     """CPU stepper with the step_tensors/reset_tensors interface; per-env inputs are functions of the GLOBAL id."""
 
+    has_reward = False      # 6-DoF: reward = 0. (6DoF.py:575) -> ShardedVecEnv builds the 37-byte message without a reward plane
+
     def __init__(self, offset, count, n_global, supports_out=False):
         from oracle import oracle as orc
         self.supports_out = supports_out
@@ -52,6 +54,8 @@ def worker(rank, world, port, n_global, mode, q, inplace=False, scatter=False):
     assert (r, w) == (rank, world)
     env = D.ShardedVecEnv(lambda off, cnt, rk: OracleShard(off, cnt, n_global, inplace), n_global, 9, torch.device("cpu"), gather=mode,
                           scatter_act_dim=6 if scatter else None)
+    if env.gather is not None:   # obs 36 B + done 1 B per env, no reward plane
+        assert not env.gather.reward_plane and env.gather.msg_bytes == (env.gather.cmax * 37 + 15) // 16 * 16
     acts = torch.from_numpy(np.random.default_rng(9).uniform(-1, 1, size=(4, n_global, 6))).float()
     def keep(x):  # gathered outputs are views into the receive buffer, valid until the next call
         return None if x is None else (x.clone() if torch.is_tensor(x) else tuple(t.clone() for t in x))
@@ -139,6 +143,20 @@ def test_gather_single_process_passthrough():
     g.exchange()
     o, r, d = g.unpack()
     assert float(o.min()) == 2.0 and float(r.max()) == 3.0 and int(d.sum()) == 5
+
+
+def test_gather_without_reward_plane():
+    """Rigid-body message: obs | done.  The producer's reward view is scratch outside the message, receivers get zeros."""
+    g = D.OutputGather(5, 9, torch.device("cpu"), reward_plane=False)
+    assert g.msg_bytes == (5 * 36 + 5 + 15) // 16 * 16 and g.bytes_per_step() == g.msg_bytes
+    o2, r2, d2 = g.out_views()
+    o2.fill_(2.0); r2.fill_(7.0); d2.fill_(3)         # a producer may write anything into its reward output
+    g.exchange()
+    o, r, d = g.unpack()
+    assert float(o.min()) == 2.0 and float(r.abs().max()) == 0.0 and int(d.sum()) == 15
+    obs, done = torch.rand(5, 9), torch.tensor([0, 1, 0, 3, 0], dtype=torch.uint8)
+    o, r, d = g(obs, torch.zeros(5), done)
+    assert torch.equal(o, obs) and torch.equal(d, done) and not r.any()
 
 
 # ---- GatherPipeline: step k+1 overlapped with gather k on two buffers (bench.py --gpus N, with_gather) --------------------
