@@ -22,13 +22,16 @@ if REPO not in sys.path:
 
 from marinevehiclereinforcementlearning_amd import params as P  # noqa: E402  (POD structs + constants only)
 
-LIB_PATH = os.path.join(HERE, "_build", "libmvrl_oracle.so")
+# MVRL_ORACLE_LIB: another build of the same restatement (the sanitizer build of oracle/Makefile, tests/test_sanitizers.py)
+LIB_PATH = os.environ.get("MVRL_ORACLE_LIB") or os.path.join(HERE, "_build", "libmvrl_oracle.so")
 TWO_PI = 2.0 * np.pi
 
 
 def build(force=False):
     src = os.path.join(HERE, "mvrl_oracle.c")
     hdr = os.path.join(REPO, "include", "mvrl.h")
+    if os.environ.get("MVRL_ORACLE_LIB"):
+        return LIB_PATH
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
         return LIB_PATH
