@@ -205,7 +205,16 @@ def test_specialised_kernels_for_non_default_constants(oracle_mod):
         for s in range(3):
             h.step(actions[s])
         y_aot = h.get_state()[:12].copy()
+        assert h.jit_info()["compiler"] == "none" and h.jit_info()["specialized"] == 0
         assert f"jit-{flavour}" in h.specialize() and h.specialize() == h.variant        # idempotent
+        # which compiler built it, and what it made of the kernel (mvrl_jit_info, from the code object's notes): the ROCm
+        # installation's hipcc as a child process - this image has it - and no spills; the in-process hiprtc fallback of a
+        # process that has PyTorch's older comgr loaded would show 74 SGPR spills and scratch here (profiles/r02_hiprtc_vs_hipcc.txt)
+        info = h.jit_info()
+        assert info["specialized"] == 1 and info["compiler"] == "hipcc", info
+        assert info["scratch_bytes"] == 0 and info["vgpr_spills"] == 0 and info["sgpr_spills"] == 0, info
+        assert 64 <= info["vgprs"] <= (128 if info["min_waves_per_simd"] == 4 else 170) and info["lds_bytes"] == 10240, info
+        print(f"jit {flavour}: {info}")
         h.reset(init=init)
         for s in range(3):
             h.step(actions[s])
@@ -225,6 +234,24 @@ def test_specialised_kernels_for_non_default_constants(oracle_mod):
         hx.close()
 
 
+def test_hiprtc_fallback_is_reported_and_warned_about(monkeypatch):
+    """MVRL_JIT_COMPILER=hiprtc: the in-process fallback.  Whatever libhiprtc / comgr this process ends up with, mvrl_jit_info says
+    so, and MarineVecEnv warns exactly when that build spills (it then runs 8-20 % slower than the hipcc build)."""
+    import warnings
+    from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
+    monkeypatch.setenv("MVRL_JIT_COMPILER", "hiprtc")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env = MarineVecEnv("rov6", 256, vehicle_params=P.rov6_params(m=12.0, Xuu=-19.0), specialize=True)
+    j = env.jit
+    print("hiprtc build:", j)
+    assert j["compiler"] == "hiprtc" and j["specialized"] == 1 and "jit-sym" in env.variant
+    spills = j["scratch_bytes"] > 0 or j["sgpr_spills"] > 0 or j["vgpr_spills"] > 0
+    assert spills == any("spills" in str(x.message) for x in w), (j, [str(x.message) for x in w])
+    env.step_tensors(env.reset_tensors().new_zeros((256, 6)))          # and it runs
+    env.close()
+
+
 def test_specialised_kernel_through_vec_env_with_turbulence_chains_and_rollouts():
     """MarineVecEnv(specialize=True) with the turbulence table: lane-range chains and K-step roll-outs of the run-time compiled
     kernel are bit-identical to its whole-batch single steps (one function serves all three), auto-resets included."""
@@ -241,6 +268,7 @@ def test_specialised_kernel_through_vec_env_with_turbulence_chains_and_rollouts(
         return MarineVecEnv("rov6", n, seed=4, maxSteps=5, flow=f, infos="lean", vehicle_params=p6, specialize=True)
     ea, eb, ec = mk(), mk(), mk()
     assert ea.variant == "rov6/jit-generic/faithful+flow"
+    assert ea.jit["compiler"] == "hipcc" and ea.jit["scratch_bytes"] == 0, ea.jit
     # specialize="auto" is the default for non-default constants; False keeps the ahead-of-time kernel
     auto = MarineVecEnv("rov6", 64, vehicle_params=p6)
     aot = MarineVecEnv("rov6", 64, vehicle_params=p6, specialize=False)

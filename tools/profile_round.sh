@@ -23,6 +23,7 @@ find $OUT/prof_${TAG}_kt -name "*_kernel_trace.csv" -delete     # the per-dispat
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_kt1 -- python3 $ARGS --chains 1 > $OUT/prof_${TAG}_kt1.json 2> $OUT/prof_${TAG}_kt1.err
 rc=$?; echo "kt1 rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
 find $OUT/prof_${TAG}_kt1 -name "*_kernel_trace.csv" -delete
+if [ "${MVRL_PROFILE_PMC:-1}" = "0" ]; then tail -c 300 $OUT/prof_${TAG}_kt.json; exit 0; fi   # kernel-trace passes only
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32" "GRBM_GUI_ACTIVE"; do
