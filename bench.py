@@ -87,10 +87,12 @@ def cpu_baseline(wl, flow_np, seed):
         init = np.concatenate([(rng.random((n, 2 * npos)) - 0.5) * 10, rng.random((n, dof - npos)) * 2 * np.pi], axis=1)
         env.reset(init, toffset=rng.random(n) * 5.0 if ft is not None else None)
         act = rng.uniform(-1, 1, size=(n, dof))
+    env.step(act)                      # first touch: thread start-up, page faults
     t0 = time.perf_counter()
-    env.step(act)
-    one = time.perf_counter() - t0
-    steps = int(max(3, min(400, 12.0 / max(one, 1e-4))))
+    for _ in range(2):
+        env.step(act)
+    one = (time.perf_counter() - t0) / 2
+    steps = int(max(3, min(2000, 15.0 / max(one, 1e-4))))     # ~15 s of CPU work
     t0 = time.perf_counter()
     for _ in range(steps):
         env.step(act)

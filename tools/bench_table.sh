@@ -24,6 +24,8 @@ run --workload c4 --precision f64 --steps 400 --warmup 40
 run --workload c4 --flavour ctrl
 run --workload c4 --flavour sym
 run --workload c4 --flavour generic
+run --workload c4 --flavour sym --specialize
+run --workload c4 --flavour generic --specialize
 run --workload c4 --rollout --steps 2000 --warmup 96
 run --workload c3
 run --workload c3 --rollout --steps 2000 --warmup 96
@@ -31,6 +33,8 @@ run --workload c2
 run --workload c2 --graph --steps 2000 --warmup 96
 run --workload c2 --rollout --steps 2000 --warmup 96
 run --workload auv
+run --workload auv --envs-per-gpu 4194304 --steps 500 --warmup 50
+run --workload auv --envs-per-gpu 4194304 --chains 1 --steps 500 --warmup 50
 run --workload auv --rollout --steps 2000 --warmup 96
 run --workload auvcyl
 run --workload loop --steps 1000 --warmup 50
