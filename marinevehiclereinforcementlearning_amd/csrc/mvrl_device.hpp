@@ -174,6 +174,14 @@ struct FlowDev {
     int n_t, n_y, n_x;
     float inv_dt, inv_dx, inv_dy;
     float t_quarter;      // flow.time[n_t // 4]  (verySimpleAuv.py:245)
+    // 0: ReconstructedFlow.interp as it is (AuvEnv, mvrl_flow_interp): indices clamped, weights not - linear EXTRAPOLATION outside
+    //    the table.  AuvEnv ends an episode 1 m from the origin after at most 5 s, so it never gets far outside.
+    // 1: the 3/6-DoF + turbulence composition (no reference counterpart).  Those vehicles are free to leave the
+    //    3.3 m x 2.2 m table and their 50-s episodes outlast its 44 s; extrapolated linearly the "current" grows without bound -
+    //    measured with the fp64 oracle on BASELINE configs[3]: 11 % of the envs non-finite after 100 steps, all of them after 224
+    //    (DESIGN.md section 1).  Outside the table the composition therefore HOLDS the boundary value in space and REFLECTS time
+    //    (t -> triangle wave over the table's duration: continuous, unsteady for any episode length); inside it is interp exactly.
+    int bounded;
 };
 
 // ReconstructedFlow.interp restricted to (u, v) (tag/flowGenerator.py:97-136): cell index clamped, weights NOT
@@ -187,6 +195,13 @@ struct FlowTap {
 __device__ __forceinline__ FlowTap flow_gather(const FlowDev& f, float time, float x, float y) {
     FlowTap g;
     float tt = time * f.inv_dt, xx = x * f.inv_dx, yy = y * f.inv_dy;
+    if (f.bounded) {   // wave-uniform
+        const float per = (float)(f.n_t - 1);
+        const float m = tt - 2.f * per * floorf(tt / (2.f * per));   // [0, 2 per)
+        tt = per - fabsf(m - per);                                   // triangle wave over [0, per]
+        xx = clampf(xx, 0.f, (float)(f.n_x - 1));
+        yy = clampf(yy, 0.f, (float)(f.n_y - 1));
+    }
     int kk = min(f.n_t - 2, max(0, (int)floorf(tt)));
     int ii = min(f.n_x - 2, max(0, (int)floorf(xx)));
     int jj = min(f.n_y - 2, max(0, (int)floorf(yy)));

@@ -114,7 +114,8 @@ class MarineVecEnv:
                 warnings.warn(f"mvrl_specialize failed, keeping the run-time-constant kernel ({self._h.variant}): {e}")
         self.has_reward = self.model == P.MODEL_AUV      # the rigid-body environments return reward = 0. (6DoF.py:575, 3DoF.py:495)
         self.jit = self._h.jit_info()     # compiler / registers / spills of a run-time compiled kernel ("none": ahead of time)
-        if self.jit["specialized"] and (self.jit["scratch_bytes"] > 0 or self.jit["sgpr_spills"] > 0 or self.jit["vgpr_spills"] > 0):
+        # a handful of SGPRs parked in VGPR lanes are harmless; scratch memory, VGPR spills or dozens of SGPR spills are not
+        if self.jit["specialized"] and (self.jit["scratch_bytes"] > 0 or self.jit["sgpr_spills"] > 16 or self.jit["vgpr_spills"] > 0):
             import warnings
             warnings.warn(f"mvrl_specialize: the {self.jit['compiler']} build of the step kernel spills ({self.jit['sgpr_spills']} SGPR, "
                           f"{self.jit['vgpr_spills']} VGPR, {self.jit['scratch_bytes']} B scratch at {self.jit['min_waves_per_simd']} waves per SIMD) - "

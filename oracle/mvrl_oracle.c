@@ -12,7 +12,8 @@
  * known-answer triple the reference holds (example_temp.py:19-28 -> g14).  tests/test_oracle_*.py checks
  * every function below against them.  The 3/6-DoF "+ turbulence current" branches (cur != 0) have no
  * reference counterpart (dead code behind np.zeros, 6DoF.py:258 / 3DoF.py:183): parity by construction
- * only.
+ * only; outside the table that composition holds the boundary value in space and
+ * reflects time (orc_flow_sample_bounded) instead of extrapolating, see DESIGN.md section 1.
  *
  * Compiled twice (oracle/Makefile): -DREAL=double -DSUF=_f64 and -DREAL=float -DSUF=_f32.  Time variables
  * stay double in both builds (they are host-side Python floats in the reference).
@@ -648,6 +649,21 @@ void FN(orc_flow_interp)(const real* table, int n_t, int n_y, int n_x, int n_com
     }
 }
 
+/* The 3/6-DoF + turbulence composition (no reference counterpart): inside the table exactly
+ * interp; outside it the boundary value is HELD in space and time is REFLECTED (triangle wave over the table's duration), because
+ * those vehicles leave the 3.3 m x 2.2 m table and their 50-s episodes outlast its 44 s - extrapolated linearly the current grows
+ * without bound and every env ends non-finite.  Same arithmetic as flow_gather (mvrl_device.hpp) with f.bounded = 1. */
+void FN(orc_flow_sample_bounded)(const real* table, int n_t, int n_y, int n_x, int n_comp, double fdt, double fdx, double fdy,
+                                 real time, real x, real y, real* out) {
+    real tt = time / (real)fdt, xx = x / (real)fdx, yy = y / (real)fdy;
+    const real per = (real)(n_t - 1);
+    const real m = tt - 2 * per * (real)floor((double)(tt / (2 * per)));
+    tt = per - (real)fabs((double)(m - per));
+    xx = xx < 0 ? 0 : (xx > (real)(n_x - 1) ? (real)(n_x - 1) : xx);
+    yy = yy < 0 ? 0 : (yy > (real)(n_y - 1) ? (real)(n_y - 1) : yy);
+    FN(orc_flow_interp)(table, n_t, n_y, n_x, n_comp, fdt, fdx, fdy, tt * (real)fdt, xx * (real)fdx, yy * (real)fdy, out);
+}
+
 void FN(orc_flow_interp_batch)(const real* table, int n_t, int n_y, int n_x, int n_comp, double fdt, double fdx,
                                double fdy, const real* t, const real* x, const real* y, int64_t n, real* out) {
     for (int64_t i = 0; i < n; i++) FN(orc_flow_interp)(table, n_t, n_y, n_x, n_comp, fdt, fdx, fdy, t[i], x[i], y[i], out + i * n_comp);
@@ -685,7 +701,7 @@ int FN(orc_rov_step)(int dof, const mvrl_rov6_params* p6, const mvrl_rov3_params
         real cur[2] = {0, 0};
         if (flow_table) { /* sampled once per step at the pre-step position, as verySimpleAuv.py:291 */
             real res[2];
-            FN(orc_flow_interp)(flow_table, f_nt, f_ny, f_nx, 2, f_dt, f_dx, f_dy, (real)time[e] + toffset[e], ye[0], ye[1], res);
+            FN(orc_flow_sample_bounded)(flow_table, f_nt, f_ny, f_nx, 2, f_dt, f_dx, f_dy, (real)time[e] + toffset[e], ye[0], ye[1], res);
             cur[0] = res[0]; cur[1] = res[1];
         }
         rhs_ctx c;

@@ -212,7 +212,8 @@ def test_specialised_kernels_for_non_default_constants(oracle_mod):
         # process that has PyTorch's older comgr loaded would show 74 SGPR spills and scratch here (profiles/r02_hiprtc_vs_hipcc.txt)
         info = h.jit_info()
         assert info["specialized"] == 1 and info["compiler"] == "hipcc", info
-        assert info["scratch_bytes"] == 0 and info["vgpr_spills"] == 0 and info["sgpr_spills"] == 0, info
+        # (a couple of SGPRs parked in VGPR lanes - the dense form at 3 waves per SIMD shows 2 - cost nothing; scratch would)
+        assert info["scratch_bytes"] == 0 and info["vgpr_spills"] == 0 and info["sgpr_spills"] <= 16, info
         assert 64 <= info["vgprs"] <= (128 if info["min_waves_per_simd"] == 4 else 170) and info["lds_bytes"] == 10240, info
         print(f"jit {flavour}: {info}")
         h.reset(init=init)
@@ -246,7 +247,7 @@ def test_hiprtc_fallback_is_reported_and_warned_about(monkeypatch):
     j = env.jit
     print("hiprtc build:", j)
     assert j["compiler"] == "hiprtc" and j["specialized"] == 1 and "jit-sym" in env.variant
-    spills = j["scratch_bytes"] > 0 or j["sgpr_spills"] > 0 or j["vgpr_spills"] > 0
+    spills = j["scratch_bytes"] > 0 or j["sgpr_spills"] > 16 or j["vgpr_spills"] > 0
     assert spills == any("spills" in str(x.message) for x in w), (j, [str(x.message) for x in w])
     env.step_tensors(env.reset_tensors().new_zeros((256, 6)))          # and it runs
     env.close()
@@ -365,8 +366,13 @@ def test_auvenv_reference_trajectory(base_flow, e):
     h.close()
 
 
-def test_rov6_with_turbulence_vs_oracle(oracle_mod, base_flow):
-    """The 6-DoF + current composition (no reference counterpart) against the fp64 oracle."""
+@pytest.mark.parametrize("where,pos_scale,toff_scale", [("inside the table", 0.05, 2.0), ("outside it, in space and time", 1.0, 60.0)])
+def test_rov6_with_turbulence_vs_oracle(oracle_mod, base_flow, where, pos_scale, toff_scale):
+    """The 6-DoF + current composition (no reference counterpart) against the fp64 oracle - inside the table (= the
+    reference's interp) and outside it (the vehicles start on the table's corner, so half of them are outside at once and the mean
+    current carries the rest out within the 20 steps; time offsets up to 60 s - the range of a BASELINE episode - against the
+    table's 13 s here, i.e. up to four reflections: boundary value held
+    in space, time reflected - DESIGN.md section 1)."""
     from oracle import flow_ref
     base, bdx, bdy = base_flow[:3]
     fd, dx, dy, dt = flow_ref.scale(base, bdx, bdy, BASE_DT, 11., 1., 2.)
@@ -374,8 +380,8 @@ def test_rov6_with_turbulence_vs_oracle(oracle_mod, base_flow):
     for dof in (6, 3):
         n, steps = 1024, 20
         init, actions = random_rov_batch(dof, n, steps, 31)
-        init[:, : (3 if dof == 6 else 2)] *= 0.05
-        toff = np.random.default_rng(2).random(n) * 2.0
+        init[:, : (3 if dof == 6 else 2)] *= pos_scale
+        toff = np.random.default_rng(2).random(n) * toff_scale
         h = _lib.Handle(P.make_config("rov6" if dof == 6 else "rov3", n, auto_reset=False, max_steps=10 ** 9, use_flow=True))
         h.set_flow(uv.astype(np.float32), dt, dx, dy)
         h.reset(init=init)
@@ -389,7 +395,8 @@ def test_rov6_with_turbulence_vs_oracle(oracle_mod, base_flow):
             env.step(actions[s].astype(np.float64))
             h.step(actions[s])
             audit.update(circ_err(h.get_state()[: 2 * dof].T, env.y, [3, 4, 5] if dof == 6 else [2]).max(axis=1), env.margins)
-        print(f"dof {dof} + current: " + audit.report())
+        assert np.isfinite(env.y).all() and np.abs(env.y[:, dof:dof + 2]).max() < 5.0      # a bounded current, bounded speeds
+        print(f"dof {dof} + current ({where}): " + audit.report())
         audit.assert_explained(max_share=0.006, max_smooth_share=0.001,
                                resolver=make_resolver(oracle_mod, dof, init, actions, dict(flow=env.flow), toffset=toff))
         h.close()

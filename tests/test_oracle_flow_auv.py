@@ -100,3 +100,45 @@ def test_auvenvcyl_trajectory(oracle_mod, base_flow, e):
         assert abs(rew[0] - g["reward"][e, s]) < 1e-9 * max(1, abs(g["reward"][e, s])), s
         assert bool(done[0]) == bool(g["done"][e, s]), s
     assert g["iwp"][e, -1] >= g["iwp0"][e]
+
+
+def test_bounded_sampling_of_the_rigid_body_composition(oracle_mod, base_flow):
+    """orc_flow_sample_bounded (the 3/6-DoF + turbulence composition): inside the table it IS interp; outside it
+    holds the boundary value in space and reflects time - and an episode of BASELINE configs[3] stays finite with it (with linear
+    extrapolation every env of that workload ends non-finite)."""
+    import ctypes as C
+    from oracle import flow_ref
+    base, bdx, bdy = base_flow
+    fd, dx, dy, dt = flow_ref.scale(base, bdx, bdy, BASE_DT, 11., 1., 2.)
+    uv = np.ascontiguousarray(fd[..., :2])
+    nt, ny, nx = uv.shape[:3]
+    o = oracle_mod.Oracle("f64")
+    f = o._f("orc_flow_sample_bounded")
+    f.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_double] * 6 + [C.c_void_p]
+    f.restype = None
+
+    def sample(t, x, y):
+        out = np.zeros(2)
+        f(uv.ctypes.data, nt, ny, nx, 2, dt, dx, dy, float(t), float(x), float(y), out.ctypes.data)
+        return out
+    T, X, Y = (nt - 1) * dt, (nx - 1) * dx, (ny - 1) * dy
+    rng = np.random.default_rng(8)
+    for _ in range(200):                                   # inside: identical to ReconstructedFlow.interp's restatement
+        t, x, y = rng.random() * T, rng.random() * X, rng.random() * Y
+        assert np.max(np.abs(sample(t, x, y) - o.flow_interp(uv, dt, dx, dy, [t], [x], [y])[0])) < 1e-12
+    for _ in range(200):                                   # outside: boundary value held, time reflected
+        t, x, y = rng.random() * T, (rng.random() - 0.5) * 40, (rng.random() - 0.5) * 40
+        inside = o.flow_interp(uv, dt, dx, dy, [t], [np.clip(x, 0, X)], [np.clip(y, 0, Y)])[0]
+        assert np.max(np.abs(sample(t, x, y) - inside)) < 1e-12
+        for k in (1, 2, 5):
+            assert np.max(np.abs(sample(2 * k * T + t, x, y) - inside)) < 1e-9      # period 2 T
+            assert np.max(np.abs(sample(2 * k * T - t, x, y) - inside)) < 1e-9      # mirror image
+    assert np.abs(sample(1e4, -1e3, 1e3)).max() < 10.0     # bounded wherever it is asked
+    # one whole 250-step episode of the 6-DoF + turbulence workload: finite, speeds of the order of the current
+    n = 512
+    env = oracle_mod.OracleRovEnv(6, n, "f64", max_steps=10 ** 9, flow=oracle_mod.FlowTable(uv, dt, dx, dy))
+    env.reset(np.concatenate([(rng.random((n, 6)) - 0.5) * 10, rng.random((n, 3)) * 2 * np.pi], axis=1), toffset=rng.random(n) * 11.0)
+    for s in range(250):
+        env.step(rng.uniform(-1, 1, (n, 6)))
+    assert np.isfinite(env.y).all() and np.abs(env.y[:, 6:9]).max() < 5.0
+    assert np.abs(env.y[:, 0]).max() > 10.0                # ... although the vehicles ARE carried far outside the 3.3 m table
