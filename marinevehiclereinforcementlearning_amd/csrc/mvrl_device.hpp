@@ -178,7 +178,7 @@ struct FlowDev {
     //    the table.  AuvEnv ends an episode 1 m from the origin after at most 5 s, so it never gets far outside.
     // 1: the 3/6-DoF + turbulence composition (no reference counterpart).  Those vehicles are free to leave the
     //    3.3 m x 2.2 m table and their 50-s episodes outlast its 44 s; extrapolated linearly the "current" grows without bound -
-    //    measured with the fp64 oracle on BASELINE configs[3]: 11 % of the envs non-finite after 100 steps, all of them after 224
+    //    measured in fp64 on BASELINE configs[3]: 11 % of the envs non-finite after 100 steps, all of them after 224
     //    (DESIGN.md section 1).  Outside the table the composition therefore HOLDS the boundary value in space and REFLECTS time
     //    (t -> triangle wave over the table's duration: continuous, unsteady for any episode length); inside it is interp exactly.
     int bounded;
