@@ -96,6 +96,25 @@ __device__ __forceinline__ void pid6(PP p, const float* z, Pid6& s, float half_d
 #else
     e[5] = angle_error(z5, 0.f);
 #endif
+    // Integrator wind-up (6DoF.py:68: eInt[abs(e) > windup] = 0).  In the action mode an error starts its step at a * scale (0.9 m,
+    // 0.79 rad) against limits of 2 m and pi / 2, so a lane beyond a limit is the exception: ONE wave-level test (two max3, two
+    // compares) decides whether the six per-axis compare-and-selects run at all.  Same result as the reference's rule in every
+    // case; the fixed-set-point flavour, whose attitude errors sit beyond the limit all the time, keeps the plain form.
+    bool windup_any = true;
+#if !MVRL_F64 && !defined(MVRL_NO_WINDUP_VOTE)
+    if (!fixed && p->windup[0] == p->windup[1] && p->windup[1] == p->windup[2] && p->windup[3] == p->windup[4] && p->windup[4] == p->windup[5]) {
+        const float m_pos = fmaxf(fmaxf(fabsf(e[0]), fabsf(e[1])), fabsf(e[2])), m_ang = fmaxf(fmaxf(fabsf(e[3]), fabsf(e[4])), fabsf(e[5]));
+        windup_any = __any((m_pos > p->windup[0]) || (m_ang > p->windup[3])) != 0;
+    }
+#endif
+    if (HAS_DT) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) s.eint[i] = fmaf(s.eold[i] + e[i], half_dtp, s.eint[i]);
+    }
+    if (windup_any) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
+    }
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         float de = e[i] - s.eold[i];
@@ -111,8 +130,6 @@ __device__ __forceinline__ void pid6(PP p, const float* z, Pid6& s, float half_d
             de = use ? di : de;
 #endif
         }
-        if (HAS_DT) s.eint[i] = fmaf(s.eold[i] + e[i], half_dtp, s.eint[i]);
-        s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
         const float kdi = HAS_DT ? kd_inv[i] : p->kd[i] * 1e9f;
         float v = fmaf(p->ki[i], s.eint[i], fmaf(kdi, de, p->kp[i] * e[i]));
         u[i] = clampf(v, -p->umax[i], p->umax[i]);
