@@ -33,6 +33,10 @@ for rnd in range(args.rounds):
         env = dict(os.environ)
         if lib:
             env["MVRL_LIB"] = lib
+        while extra and "=" in extra[0] and not extra[0].startswith("-"):     # leading KEY=value words of an arm: environment
+            k_, v_ = extra[0].split("=", 1)
+            env[k_] = v_
+            extra = extra[1:]
         r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + shlex.split(args.common) + extra, env=env,
                            capture_output=True, text=True)
         try:
