@@ -491,9 +491,10 @@ def main():
         es = 8 if args.precision == "f64" else 4
         working_set = n * (state_words * es + obs_dim * es + es + 1 + act_dim * es)
         auv_note = ("HBM-bound kernel; working set of a step (state planes + outputs + one action batch) %.0f MB " % (working_set / 1e6) +
-                    ("FITS the 256 MB Infinity Cache: the plane traffic is served from it, above what HBM streams at - `frac` is "
-                     "then a fraction of the HBM peak but not an HBM measurement (see the %d-env run in profiles/r03_bench_table.txt)" % 4194304
-                     if working_set <= 256e6 else
+                    ("is of the size of the 256 MB Infinity Cache: part of the plane traffic is served from it, above what HBM streams at - "
+                     "`frac` is then a fraction of the HBM peak but not a pure HBM measurement (see the %d-env run in "
+                     "profiles/r03_bench_table.txt)" % 4194304
+                     if working_set <= 512e6 else
                      "exceeds the 256 MB Infinity Cache several times over: the plane traffic comes from HBM"))
         launch_desc = ("one launch per 250-step episode batch" if pd_obj is not None else
                        "mvrl_rollout_dev: %d env steps per call" % RING if roll_out is not None else
