@@ -191,7 +191,12 @@ void mvrl_destroy(mvrl_handle* h);
  * Replaces the table held by ReconstructedFlow after scale() (flowGenerator.py:76-95).  The handle keeps its own copy in
  * the layout its kernels read - the 2 x 2 x 2 interpolation stencil of every cell in one 64-byte cache line: eight times
  * the table's size in device memory (320 MB for 2000 snapshots of 41 x 61), one instead of 4.5 scattered cache lines per
- * lookup. */
+ * lookup.
+ * How the step kernels sample it: AuvEnv / AuvEnvCyl handles exactly as ReconstructedFlow.interp does (flowGenerator.py:97-136:
+ * cell index clamped, weights not - linear extrapolation outside the table).  3-/6-DoF handles (the "+ turbulence" composition,
+ * which has no reference counterpart) sample it like interp INSIDE the table and, outside it, hold the boundary value in space and
+ * reflect time over the table's duration: those vehicles leave the table and their episodes outlast it, and extrapolated
+ * linearly the current grows without bound.  mvrl_flow_interp below is interp itself. */
 int mvrl_set_flow(mvrl_handle* h, const float* table_host, const mvrl_flow_desc* desc);
 int mvrl_set_flow_f64(mvrl_handle* h, const double* table_host, const mvrl_flow_desc* desc);
 /* Same, table already resident on the handle's device in the handle's precision (read once, here: later changes to the
