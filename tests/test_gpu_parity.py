@@ -224,6 +224,29 @@ def test_specialised_kernels_for_non_default_constants(oracle_mod):
         assert np.median(d.max(axis=0)) < 2e-6, np.median(d.max(axis=0))
         _audited_run(oracle_mod, 6, h, n, steps, init, actions, rov6=p6, control_mode=mode)
         h.close()
+    # fixed set-point mode is a kernel flavour of its own (template flag FIXED: displacement coordinates + E0 in LDS): the
+    # run-time compiled kernel is built for the handle's mode and agrees with the ahead-of-time one and with the oracle
+    p6 = P.rov6_params(m=12.0, Xuu=-19.0)
+    hf = _lib.Handle(P.make_config("rov6", n, fixed_setpoint=True, auto_reset=False, max_steps=10 ** 9, use_flow=False, rov6=p6))
+    hf.reset(init=init)
+    for s in range(5):
+        hf.step(actions[s])
+    y_aot = hf.get_state()[:12].copy()
+    assert "jit-sym" in hf.specialize() and hf.jit_info()["compiler"] == "hipcc"
+    hf.reset(init=init)
+    for s in range(5):
+        hf.step(actions[s])
+    assert np.median(np.abs(hf.get_state()[:12] - y_aot).max(axis=0)) < 2e-6
+    env = oracle_mod.OracleRovEnv(6, n, "f64", max_steps=10 ** 9, fixed_setpoint=True, rov6=p6)
+    env.reset(init.astype(np.float64))
+    hf.reset(init=init)
+    worst = 0.0
+    for s in range(8):
+        env.step(actions[s].astype(np.float64))
+        hf.step(actions[s])
+        worst = max(worst, float(np.median(circ_err(hf.get_state()[:12].T, env.y, [3, 4, 5]).max(axis=1))))
+    assert worst < 2e-6, worst
+    hf.close()
     # default constants: nothing to do; other models and precisions: refused
     hb = _lib.Handle(P.make_config("rov6", 64, use_flow=False))
     assert hb.specialize() == hb.variant and "baked" in hb.variant
