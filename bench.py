@@ -92,7 +92,7 @@ def cpu_baseline(wl, flow_np, seed):
     for _ in range(2):
         env.step(act)
     one = (time.perf_counter() - t0) / 2
-    steps = int(max(3, min(2000, 15.0 / max(one, 1e-4))))     # ~15 s of CPU work
+    steps = int(max(3, min(2000, 10.0 / max(one, 1e-4))))     # 10-20 s of CPU work (later steps run slower than the first warm ones)
     t0 = time.perf_counter()
     for _ in range(steps):
         env.step(act)
