@@ -541,7 +541,8 @@ def main():
                          "note": ("fused episodes: the bytes are the turbulence gathers (L2 / Infinity-Cache resident), the kernel is "
                                   "bound by instruction issue, not HBM" if pd_obj is not None else
                                   auv_note if wl["model"].startswith("auv") else
-                                  "the binding roof of this kernel is VALU issue (`valu`); the HBM fraction is reported as the "
+                                  "this kernel is bound by board power at the VALU (time follows the executed-instruction count - `valu` - "
+                                  "and the operands' switching: DESIGN.md section 5), not by HBM; the HBM fraction is reported as the "
                                   "contract asks") + "; kernel_us_per_step = HIP-event time of the median K-step region / K "
                                  "(wall time on the GPU: launch gaps, ramps and tails included)"},
             "outputs_finite": finite,
