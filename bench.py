@@ -139,7 +139,7 @@ def self_launch(n_ranks, argv=None):
     def code(p):
         return None if p.returncode is None else (p.returncode if p.returncode >= 0 else 128 - p.returncode)
 
-    grace, first_bad = 30.0, None
+    grace, first_bad = float(os.environ.get("MVRL_LAUNCH_GRACE_S", "30")), None
     try:
         while any(p.poll() is None for p in procs):
             bad = [p for p in procs if p.returncode not in (None, 0)]

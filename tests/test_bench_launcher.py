@@ -40,6 +40,27 @@ def test_ranks_get_the_torchrun_environment_and_the_worst_exit_code_wins(tmp_pat
     assert "rank 1 1 3 127.0.0.1 True" in r.stderr and "rank 2 2 3 127.0.0.1 True" in r.stderr
 
 
+def test_a_dead_rank_takes_the_hung_ones_with_it(tmp_path):
+    """A rank that dies while the others wait for it (a broken rendezvous) must not hang the job: the launcher kills the survivors
+    after its grace period and reports the failure."""
+    import time
+    prog = tmp_path / "hang_probe.py"
+    prog.write_text(
+        "import os, sys, time, importlib.util\n"
+        f"spec = importlib.util.spec_from_file_location('bench', {os.path.join(REPO, 'bench.py')!r})\n"
+        "bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)\n"
+        "if 'WORLD_SIZE' not in os.environ:\n"
+        "    bench.__file__ = os.path.abspath(__file__)\n"
+        "    sys.exit(bench.self_launch(2, argv=[]))\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    sys.exit(7)\n"
+        "time.sleep(600)\n")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, str(prog)], capture_output=True, text=True, env=dict(_env(), MVRL_LAUNCH_GRACE_S="1.5"), timeout=120)
+    assert r.returncode != 0 and time.monotonic() - t0 < 60, (r.returncode, time.monotonic() - t0)
+    assert r.returncode == 128 + 9        # the worst code: the SIGKILL the launcher handed to the hung rank (rank 0's own was 7)
+
+
 def test_no_gpu_no_result():
     """Without a GPU the plain N = 2 command fails loudly in both ranks (no CPU fallback) and prints no JSON line."""
     import torch
