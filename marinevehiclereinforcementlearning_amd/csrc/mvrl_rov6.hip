@@ -447,6 +447,32 @@ __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, con
 #undef MVRL_FULL_TRIG
 }
 
+// The third RK stage sits at y + h/2 k2, the second at y + h/2 k1: their attitudes differ by eps = h/2 (k2 - k1) - the very
+// increment the PID of stage 3 differentiates, a few milliradians - so stage 3 rotates STAGE 2's sines and cosines by it with
+// short polynomials (9 instructions per angle instead of 12; |eps| <= 0.05: truncation 3e-9 in sin, 2e-11 in cos; one more
+// rounding than a rotation from the base attitude).  A lane with a larger eps takes the general path from the base attitude.
+template <class SP>
+__device__ __forceinline__ Trig6 stage3_trig(const Trig6& t2, const Trig6& tb, const float* yt, const float* eps, const float* d2, const SP& sp) {
+#if MVRL_F64 || defined(MVRL_FULL_STAGE_TRIG) || defined(MVRL_NO_STAGE3_SMALL)
+    return stage_trig<true>(tb, yt, d2, sp);
+#else
+    Trig6 t;
+    float sd[3], cd[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float r = eps[3 + k], r2 = r * r;
+        sd[k] = r * fmaf(r2, -1.666666667e-1f, 1.0f);
+        cd[k] = fmaf(r2, fmaf(r2, 4.166666667e-2f, -0.5f), 1.0f);
+    }
+    t.sph = fmaf(t2.cph, sd[0], t2.sph * cd[0]); t.cph = fmaf(-t2.sph, sd[0], t2.cph * cd[0]);
+    t.sth = fmaf(t2.cth, sd[1], t2.sth * cd[1]); t.cth = fmaf(-t2.sth, sd[1], t2.cth * cd[1]);
+    t.sps = fmaf(t2.cps, sd[2], t2.sps * cd[2]); t.cps = fmaf(-t2.sps, sd[2], t2.cps * cd[2]);
+    const float m = fmaxf(fmaxf(fabsf(eps[3]), fabsf(eps[4])), fabsf(eps[5]));
+    if (m > 0.05f) t = stage_trig<true>(tb, yt, d2, sp);
+    return t;
+#endif
+}
+
 // One RHS evaluation in FAITHFUL mode = BlueROV2Heavy6DoF.derivs (6DoF.py:406-442), PID state mutated.
 // timeHistory columns F0..F5 (controller output) and u0..u7 (rpm) of the LAST derivs call of a step (6DoF.py:578-587)
 template <class PP>
@@ -810,7 +836,8 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]);
 #pragma unroll
                 for (int q = 0; q < 6; q++) dp[q] = hh * k[q];
-                derivs6<SYM, FLOW, true, true>(p, yt, stage_trig<true>(tb, yt, dp, sps), pid, half_dtp, kd_inv, dp, true, cur, k, nullptr, fixed, e0s);
+                const Trig6 t2 = stage_trig<true>(tb, yt, dp, sps);
+                derivs6<SYM, FLOW, true, true>(p, yt, t2, pid, half_dtp, kd_inv, dp, true, cur, k, nullptr, fixed, e0s);
                 float d2[6], d3[6], a[12], yb[12];
                 park_a.get(a);
 #pragma unroll
@@ -821,7 +848,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_y.get(yb);
 #pragma unroll
                 for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], yb[q]);
-                derivs6<SYM, FLOW, false, true>(p, yt, stage_trig<true>(tb, yt, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, nullptr, fixed, e0s);
+                derivs6<SYM, FLOW, false, true>(p, yt, stage3_trig(t2, tb, yt, dp, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, nullptr, fixed, e0s);
 #pragma unroll
                 for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
                 park_a.get(a);
@@ -847,13 +874,14 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]); }
 #pragma unroll
             for (int q = 0; q < 6; q++) dp[q] = hh * k[q];                       // (y + hh k1) - y
-            derivs6<SYM, FLOW, true, true>(p, yt, stage_trig<true>(tb, yt, dp, sps), pid, half_dtp, kd_inv, dp, true, cur, k, nullptr, fixed, e0s);
+            const Trig6 t2 = stage_trig<true>(tb, yt, dp, sps);
+            derivs6<SYM, FLOW, true, true>(p, yt, t2, pid, half_dtp, kd_inv, dp, true, cur, k, nullptr, fixed, e0s);
             float d2[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }  // hh (k2 - k1)
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]); }
-            derivs6<SYM, FLOW, false, true>(p, yt, stage_trig<true>(tb, yt, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, nullptr, fixed, e0s);
+            derivs6<SYM, FLOW, false, true>(p, yt, stage3_trig(t2, tb, yt, dp, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, nullptr, fixed, e0s);
             float d3[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }          // h k3 - hh k2
