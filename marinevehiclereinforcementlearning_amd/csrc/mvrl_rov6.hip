@@ -351,7 +351,13 @@ __device__ __forceinline__ Trig6 trig6_err(const SP& sps, const float* z) {
 #ifdef MVRL_JIT_MIN_WAVES   /* mvrl_specialize: literal constants need no SGPR headroom; the dense form is tried at 4 waves first */
 #define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, MVRL_JIT_MIN_WAVES)
 #else
-#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, SYM ? 4 : 2)
+// Four waves per SIMD (128 VGPRs) for the literal-constant flavour; the flavours that read constants at run time keep them in
+// SGPRs, of which a wave has ~100, and at 128 VGPRs the excess is parked in VGPR lanes or scratch (r3: 19-28 SGPR spills, 12 B of
+// scratch in the ctrl flavour) - MVRL_RT_WAVES lets them have more registers instead (measured: see DESIGN.md section 5).
+#ifndef MVRL_RT_WAVES
+#define MVRL_RT_WAVES 4
+#endif
+#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, SYM ? (same_type<PP, const Rov6Baked*>::value ? 4 : MVRL_RT_WAVES) : 2)
 #endif
 // LDS per block = 10 KB although the parked tiles need 6: 160 KB / 10 KB = 16 one-wave blocks per CU = exactly four waves
 // per SIMD.  A kernel instance that happens to need <= 96 VGPRs would otherwise get a FIFTH wave, and five waves rotate
