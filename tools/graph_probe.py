@@ -39,4 +39,17 @@ for model, n, use_flow in (("rov6", 1048576, True), ("rov3", 65536, False), ("ro
         g.replay()
     torch.cuda.synchronize()
     t_graph = (time.perf_counter() - t0) / K
-    print(f"{model} n={n}: plain {t_plain*1e6:.2f} us/step, graph of {R} steps {t_graph*1e6:.2f} us/step ({t_plain/t_graph:.3f}x)")
+    # a graph of ONE step, replayed per step: what a per-call graph inside mvrl_step_dev could buy VecEnv.step
+    g1 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1, stream=s):
+        plain(1)
+    for _ in range(200):
+        g1.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        g1.replay()
+    torch.cuda.synchronize()
+    t_g1 = (time.perf_counter() - t0) / K
+    print(f"{model} n={n}: plain {t_plain*1e6:.2f} us/step, graph of {R} steps {t_graph*1e6:.2f} us/step ({t_plain/t_graph:.3f}x), "
+          f"graph of 1 step replayed per step {t_g1*1e6:.2f} us/step")
