@@ -453,7 +453,6 @@ __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, con
 #undef MVRL_FULL_TRIG
 }
 
-// (Also used for the next sub-step's base attitude, rotated from the fourth stage's.)
 // The third RK stage sits at y + h/2 k2, the second at y + h/2 k1: their attitudes differ by eps = h/2 (k2 - k1) - the very
 // increment the PID of stage 3 differentiates, a few milliradians - so stage 3 rotates STAGE 2's sines and cosines by it with
 // short polynomials (9 instructions per angle instead of 12; |eps| <= 0.05: truncation 3e-9 in sin, 2e-11 in cos; one more
@@ -873,9 +872,11 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 for (int q = 0; q < 6; q++) { d2[q] = h6 * (a[q] + k[q]); inc_prev[q] = d2[q] - d3[q]; }
 #pragma unroll
                 for (int q = 0; q < 12; q++) y[q] = fmaf(q < 6 ? -h6 : h6, a[q] + k[q], yb[q]);
-#ifndef MVRL_NO_TB_FROM_STAGE4
-                // the next sub-step's base attitude = the fourth stage's, rotated by y_new - (y + h k3) (= inc_prev, milliradians:
-                // the short polynomials of stage3_trig) instead of the old base rotated by the whole sub-step's increment
+#ifdef MVRL_TB_FROM_STAGE4
+                // Experiment, NOT adopted: the next sub-step's base attitude = the fourth stage's, rotated by
+                // y_new - (y + h k3) (= inc_prev, milliradians) with the short polynomials of stage3_trig.  -29 instructions per env
+                // step, no measurable time, same error distribution at n_sub 4 - but it doubles the links of the base-attitude chain
+                // and moved a slowly drifting n_sub-8 env from 7.8e-5 to 1.0e-4.
                 if (((ks + 1) & 3) != 0 && ks + 1 < io.n_sub) tb = stage3_trig(t4, tb, y, inc_prev, d2, sps);
 #else
                 if (((ks + 1) & 3) != 0 && ks + 1 < io.n_sub) tb = stage_trig<true>(tb, y, d2, sps);

@@ -34,7 +34,7 @@ VARIANTS = {
     "w3": dict(extra=["-DMVRL_MIN_WAVES=3"], drop=()),
     "w4": dict(extra=["-DMVRL_MIN_WAVES=4"], drop=()),                # spills
     "rt3": dict(extra=["-DMVRL_RT_WAVES=3"], drop=()),                # run-time-constant structured flavours (ctrl, sym) at 3 waves per SIMD
-    "notb4": dict(extra=["-DMVRL_NO_TB_FROM_STAGE4"], drop=()),       # next base attitude rotated from the old base by the whole sub-step increment (before r3)
+    "tb4": dict(extra=["-DMVRL_TB_FROM_STAGE4"], drop=()),            # experiment (not adopted): next base attitude rotated from the fourth stage's
     "nos3": dict(extra=["-DMVRL_NO_STAGE3_SMALL"], drop=()),          # stage-3 attitude rotated from the base attitude like the other stages
     "novote": dict(extra=["-DMVRL_NO_WINDUP_VOTE"], drop=()),         # per-axis wind-up compare-and-select at every PID call (round-2 behaviour)
     "noyaw": dict(extra=["-DMVRL_NO_YAW_INC"], drop=()),              # fresh angle reduction of the yaw error at every PID call (round-2 behaviour)
