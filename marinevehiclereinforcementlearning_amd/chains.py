@@ -8,7 +8,7 @@ every launch, plus the few microseconds between two dependent launches, leave a 
 `ChainStepper` splits the batch into `n_chains` contiguous lane ranges and steps each range on its own stream through
 `mvrl_step_range_dev`: chain A's launch k+1 only waits for chain A's launch k, and while it drains and the next one
 ramps up, chain B's kernel keeps the SIMDs busy.  With a policy in the loop the same structure overlaps policy(A) with
-step(B).  Results are bit-identical to whole-batch steps (a lane's arithmetic does not depend on the launch geometry).
+step(B): `closed_loop(policy, steps)` runs one policy -> step loop per chain.  Results are bit-identical to whole-batch steps (a lane's arithmetic does not depend on the launch geometry).
 
     stepper = ChainStepper(env, n_chains=2)
     stepper.fork()                        # chains start behind the work already queued on the current stream
@@ -68,3 +68,39 @@ class ChainStepper:
         cur = torch.cuda.current_stream()
         for s in self.streams:
             cur.wait_stream(s)
+
+    def closed_loop(self, policy, steps, actions=None):
+        """`steps` env steps with a device-resident policy IN the loop, one loop per chain:
+
+            chain c, on its own stream:   a_c = policy(obs[lo_c:hi_c]);  step lanes [lo_c, hi_c) with a_c;  repeat
+
+        `policy(obs_slice) -> actions_slice` must act row by row (an MLP, the PD / LOS controllers: anything a batch can be
+        split for) and is called under `torch.cuda.stream(chain stream)`, so its kernels queue behind the chain's previous env
+        step and ahead of its next one.  Step k+1 of a chain really does depend on its step k through the policy - the data
+        dependency of every RL roll-out - but not on the OTHER chain: while chain A's policy runs and its next env launch
+        ramps up, chain B's env kernel has the chip.  Same observations, actions and states as the joined loop
+        `for k: a = policy(obs); obs = env.step_tensors(a)` (bit for bit when the policy is row-wise deterministic).
+        Starts from the observations currently in the env's output tensors (reset_tensors() / the previous step); fork() and
+        join() around the whole run are done here.  Returns (obs, reward, done, actions) of the last step.
+
+        Measured (tools/policy_loop_bench.py, profiles/r03_policy_loop.txt): with an EAGER torch policy this buys nothing - the
+        loop issues every small policy kernel once per chain and becomes bound by Python's launch overhead (C4, elementwise
+        policy: 161 vs 160 us per step; 262 144 envs: 75 vs 52) - so use it with policies that are one launch per call (the
+        mvrl_policy_* kernels, a captured graph, a compiled module), or not at all: the joined loop is the default for a reason."""
+        env = self.env
+        obs, rew, done = env._ensure_tensors()
+        rt = torch.float64 if env.handle.f64 else torch.float32
+        n, ad = env.num_envs, env.action_space.shape[0]
+        if actions is None:
+            actions = torch.empty((n, ad), dtype=rt, device=obs.device)
+        assert actions.is_contiguous() and tuple(actions.shape) == (n, ad) and actions.dtype == rt
+        ptrs = (actions.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+        launch = env.handle.step_range_dev
+        self.fork()
+        for _ in range(int(steps)):
+            for (lo, cnt), s in zip(self.ranges, self.streams):
+                with torch.cuda.stream(s):
+                    actions[lo:lo + cnt].copy_(policy(obs[lo:lo + cnt]))
+                launch(lo, cnt, *ptrs, s.cuda_stream)
+        self.join()
+        return obs, rew, done, actions

@@ -54,6 +54,38 @@ def test_chains_bit_identical_to_whole_batch_steps(model, n, chains):
     ea.close(); eb.close()
 
 
+@pytest.mark.parametrize("model,n,chains", [("rov6", 8192 + 77, 2), ("rov3", 5000, 3), ("auv", 6000, 2)])
+def test_closed_loop_with_a_policy_per_chain(model, n, chains):
+    """ChainStepper.closed_loop: a device-resident row-wise policy in the loop, one policy -> step loop per chain on its own
+    stream - the same observations, actions and final state, bit for bit, as the joined loop a = policy(obs); obs = step(a),
+    random auto-resets included (step k+1 of a chain depends on its step k through the policy, not on the other chain)."""
+    import torch
+    from marinevehiclereinforcementlearning_amd.chains import ChainStepper
+    from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
+    steps = 21
+    kw = dict(seed=3, maxSteps=8, infos="lean")
+    ea, eb = MarineVecEnv(model, n, flow=_flow(), **kw), MarineVecEnv(model, n, flow=_flow(), **kw)
+    ad, od = ea.action_space.shape[0], ea.observation_space.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    w = torch.rand((1, ad), device="cuda", generator=g) * 4 - 2
+    b = torch.rand((1, ad), device="cuda", generator=g) - 0.5
+
+    def policy(obs):          # elementwise, so row-wise deterministic whatever the slice
+        return torch.tanh(obs[:, :ad] * w + obs[:, od - ad:] * 0.5 + b)
+    oa = ea.reset_tensors()
+    eb.reset_tensors()
+    for k in range(steps):
+        a_ref = policy(oa)
+        oa, ra, da = ea.step_tensors(a_ref.contiguous())
+    st = ChainStepper(eb, n_chains=chains)
+    ob, rb, db, a_last = st.closed_loop(policy, steps)
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(a_ref, a_last)
+    assert np.array_equal(ea.get_state(), eb.get_state())
+    assert int(ea.handle.episode_counter().max()) >= 3
+    ea.close(); eb.close()
+
+
 def test_range_arguments_are_checked():
     h = _lib.Handle(P.make_config("rov6", 1000, auto_reset=False, max_steps=10))
     a = h.dev_alloc(1000 * 6 * 4); o = h.dev_alloc(1000 * 9 * 4); r = h.dev_alloc(4000); d = h.dev_alloc(1000)
