@@ -89,6 +89,20 @@ class ReconstructedFlow(object):
         out = _lib.flow_interp(self.flowData, self.dt, self.dx, self.dy, t, xy[:, 0], xy[:, 1], device=self.device)
         return out[0] if np.ndim(time) == 0 else out
 
+    def interp_bounded(self, time, xy):
+        """How the 3-/6-DoF + turbulence composition samples the table (no reference counterpart): `interp`
+        inside it; outside it the boundary value held in space and time reflected over the table's duration (triangle wave) -
+        `interp` at the clamped / reflected coordinates, exactly what the step kernels' flow_gather does with `bounded` set."""
+        t = np.atleast_1d(np.asarray(time, dtype=np.float64))
+        xy2 = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+        per = (self.nT - 1) * self.dt
+        m = np.mod(t, 2.0 * per)
+        tr = per - np.abs(m - per)
+        x = np.clip(xy2[:, 0], 0.0, (self.flowData.shape[2] - 1) * self.dx)
+        y = np.clip(xy2[:, 1], 0.0, (self.flowData.shape[1] - 1) * self.dy)
+        out = self.interp(tr, np.stack([x, y], axis=1))
+        return out[0] if np.ndim(time) == 0 else out
+
     def interpField(self, time):
         """flowGenerator.py:138-159 (time-only interpolation of the whole plane; host arithmetic on the table)."""
         tt = time / self.dt

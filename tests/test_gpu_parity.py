@@ -389,6 +389,38 @@ def test_auvenv_reference_trajectory(base_flow, e):
     h.close()
 
 
+def test_flow_interp_bounded_facade(oracle_mod, base_flow):
+    """ReconstructedFlow.interp_bounded (the composition's sampling rule, on the host facade) against the oracle's sampler, in
+    and far outside the table."""
+    import ctypes as C
+    from marinevehiclereinforcementlearning_amd.flow import ReconstructedFlow
+    from marinevehiclereinforcementlearning_amd.synthetic import synthetic_spod
+    from oracle import flow_ref
+    base, bdx, bdy = base_flow[:3]
+    g = golden("g12_flow_interp.npz")
+    modes, coeffs = synthetic_spod(int(g["K"]), int(g["nT"]))
+    flow = ReconstructedFlow(modes=modes, coeffs=coeffs, lt_mean=np.load(os.path.join(GOLDEN, "ltm.npy")),
+                             coords=np.load(os.path.join(GOLDEN, "turbulence_coords.npy")))
+    flow.scale(11., 1., 2., translate=(-1.65, -1.1))
+    fd, dx, dy, dt = flow_ref.scale(base, bdx, bdy, BASE_DT, 11., 1., 2.)
+    uv = np.ascontiguousarray(fd[..., :2])
+    o = oracle_mod.Oracle("f64")
+    f = o._f("orc_flow_sample_bounded")
+    f.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_double] * 6 + [C.c_void_p]
+    f.restype = None
+    rng = np.random.default_rng(12)
+    n = 400
+    t = rng.random(n) * 80.0 - 5.0
+    xy = (rng.random((n, 2)) - 0.4) * 12.0
+    got = flow.interp_bounded(t, xy)[:, :2]
+    ref = np.zeros((n, 2))
+    for i in range(n):
+        f(uv.ctypes.data, uv.shape[0], uv.shape[1], uv.shape[2], 2, dt, dx, dy, float(t[i]), float(xy[i, 0]), float(xy[i, 1]), ref[i].ctypes.data)
+    assert np.max(np.abs(got - ref)) < 2e-5 and np.abs(got).max() < 10.0
+    one = flow.interp_bounded(3.0, [1.0, 1.0])
+    assert one.shape == (3,) and np.max(np.abs(one - flow.interp(3.0, [1.0, 1.0]))) < 1e-6      # inside the table it IS interp
+
+
 @pytest.mark.parametrize("where,pos_scale,toff_scale", [("inside the table", 0.05, 2.0), ("outside it, in space and time", 1.0, 60.0)])
 def test_rov6_with_turbulence_vs_oracle(oracle_mod, base_flow, where, pos_scale, toff_scale):
     """The 6-DoF + current composition (no reference counterpart) against the fp64 oracle - inside the table (= the
