@@ -465,7 +465,7 @@ def test_config_fuzz_vs_oracle(oracle_mod, base_flow):
     base, bdx, bdy = base_flow[:3]
     fd, fdx, fdy, fdt = flow_ref.scale(base, bdx, bdy, BASE_DT, 11., 1., 2.)
     uv = np.ascontiguousarray(fd[..., :2])
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(int(os.environ.get("MVRL_FUZZ_SEED", "2024")))     # other seeds: exploratory runs of the sweep
     sizes = [1, 63, 65, 257, 1000]
     flavours = {6: [None, dict(m=12.0, Xuu=-19.0), dict(CG=[0.01, -0.015, 0.04], Yr=-0.3)],
                 3: [None, dict(m=12.0, CG=[0.01, 0.02, 0.02], Yr=-0.2)]}
@@ -477,6 +477,12 @@ def test_config_fuzz_vs_oracle(oracle_mod, base_flow):
         # h = dt / n_sub stays <= 0.1 s: at h = 0.2 the closed loop is outside RK4's stability region and
         # amplifies the fp32 round-off of ANY implementation, which is not a parity statement
         n_sub = int(rng.choice([1, 2, 3, 4] if dt == 0.1 else [2, 3, 4, 5]))
+        while dof == 3 and dt / n_sub > 0.05:
+            # the 3-DoF closed loop (yaw inertia 0.28 kg m^2 against the same PID derivative floor) leaves RK4's stability
+            # region earlier than the 6-DoF one: exploratory seeds of this sweep (MVRL_FUZZ_SEED, tools/r3_fuzz.sh) produced yaw
+            # rates of 1e7 rad/s after two steps at h = 0.1 s and NaNs with a fixed set-point at h = 0.067 s - in the fp64
+            # oracle as much as on the GPU (a round-2 build of the 3-DoF kernel gave the same numbers).  Not a parity statement.
+            n_sub += 1
         mode = int(rng.choice([P.CTRL_FAITHFUL, P.CTRL_ZOH]))
         fixed = bool(rng.integers(0, 2))
         use_flow = bool(rng.integers(0, 2))
