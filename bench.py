@@ -104,7 +104,10 @@ def cpu_baseline(wl, flow_np, seed):
               "rov3": {"value": 6.8, "under_rk4_harness": 450.0,
                        "what": "BlueROV2Heavy3DoFEnv.step, 1 env, 1000 random-action steps (BASELINE configs[0]; 1047 derivs per step)"},
               "auv": {"value": 5600.0, "under_rk4_harness": None, "what": "AuvEnv.step with flow.interp, 5000 steps"}}[wl["model"]]
+    # how the two CPU columns relate: on ONE core of the build container the fp64 C oracle steps 8.36e4 6-DoF env-steps/s (RK4, n_sub 4),
+    # the reference's NumPy derivs under the same harness 250 - the oracle is ~330 x the reference per core
     ref_np.update({"unit": "env-steps/s", "cores": 1, "hardware": "build container, Intel Xeon 2.1 GHz, numpy 2.2.6 / scipy 1.15.3",
+                   "oracle_same_core_6dof_rk4": 8.36e4,
                    "source": "BASELINE.md section 2 (imported reference, not run on this box)"})
     return {"value": n * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n} envs x {steps} steps of the same workload, fp64 C oracle with OpenMP over envs ({el:.1f} s)",
