@@ -1,4 +1,4 @@
-"""Run under the host-ASan build of libmvrl (tests/test_sanitizers.py: LD_PRELOAD of clang's ASan runtime, MVRL_LIB=...hostasan.so,
+"""Run under the host-ASan build of libmvrl (tests/sanitize/test_sanitizers.py: LD_PRELOAD of clang's ASan runtime, MVRL_LIB=...hostasan.so,
 no GPU): every argument-checking and host-only path of the C ABI - bad configurations (the cases of tests/test_abi.py), NULL and
 mis-sized arguments, parameter narrowing for all three models, the JIT driver with both compilers, the code-object note parser, the
 child-environment scrubber.  Any ASan / UBSan finding aborts the process."""

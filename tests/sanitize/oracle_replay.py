@@ -1,4 +1,4 @@
-"""Run under the sanitizer build of the oracle (tests/test_sanitizers.py: LD_PRELOAD=libasan, MVRL_ORACLE_LIB=..._asan.so): golden
+"""Run under the sanitizer build of the oracle (tests/sanitize/test_sanitizers.py: LD_PRELOAD=libasan, MVRL_ORACLE_LIB=..._asan.so): golden
 trajectories through every family of oracle entry points - RK4 harness (FAITHFUL / ZOH / fixed set-point, 6- and 3-DoF), the
 scipy-faithful RK45 driver, the fp32 build, the turbulence lookup and AuvEnv episodes.  Any ASan / UBSan finding aborts."""
 import os

@@ -8,7 +8,7 @@ import sys
 
 import pytest
 
-from .conftest import REPO
+from ..conftest import REPO
 
 
 def _run(driver, preload, extra_env):
@@ -21,7 +21,7 @@ def _run(driver, preload, extra_env):
 
 
 def test_oracle_under_asan_ubsan():
-    subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "-s", "_build/libmvrl_oracle_asan.so"])
+    subprocess.check_call(["make", "-C", os.path.join(REPO, "oracle"), "-s", "-f", os.path.join(REPO, "tests", "sanitize", "oracle_asan.mk")])
     libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
     if not os.path.isabs(libasan):
         pytest.skip("gcc has no libasan")
@@ -30,7 +30,8 @@ def test_oracle_under_asan_ubsan():
 
 
 def test_libmvrl_host_side_under_asan_ubsan():
-    from marinevehiclereinforcementlearning_amd import _lib, build
+    from marinevehiclereinforcementlearning_amd import _lib
+    from . import build_san as build
     if _lib.device_count() > 0:
         pytest.skip("CPU-container check: the sanitizer build is never loaded next to a GPU")
     rt = build.asan_runtime()
