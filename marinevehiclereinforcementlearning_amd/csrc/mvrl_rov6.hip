@@ -190,6 +190,29 @@ __device__ __forceinline__ void allocate6(PP p, const Axes& a, const float* u, f
     }
 }
 
+// np.linalg.solve(M, RHS) (6DoF.py:428) with the constant M^-1 the host inverted in fp64 (params.py).
+// SYM: x_g = y_g = 0 and diagonal inertia leave only the (u,q) / (v,p) couplings (6DoF.py:286-299): 10 non-zeros.
+template <bool SYM, class PP>
+__device__ __forceinline__ void mass_solve6(PP p, const float* R, float* acc) {
+    if (SYM) {
+        acc[0] = p->minv[0] * R[0] + p->minv[4] * R[4];
+        acc[1] = p->minv[7] * R[1] + p->minv[9] * R[3];
+        acc[2] = p->minv[14] * R[2];
+        acc[3] = p->minv[19] * R[1] + p->minv[21] * R[3];
+        acc[4] = p->minv[24] * R[0] + p->minv[28] * R[4];
+        acc[5] = p->minv[35] * R[5];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            p = launder_after(p, i > 0 ? acc[i - 1] : R[5]);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) a = fmaf(p->minv[6 * i + j], R[j], a);
+            acc[i] = a;
+        }
+    }
+}
+
 // forceModel + solve + kinematics (6DoF.py:253-442) for given limited thruster forces.
 // rhs_out / h_out (may be null; constant-folded away in the step kernels): forceModel's second return value RHS and the
 // thruster column H of its retComp breakdown - the unit-level entry point (rov6_unit_kernel)
@@ -247,13 +270,7 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
         R[3] = fmaf(p->gw[2], ax.k1, R[3]);
         R[4] = fmaf(-p->gw[2], t.sth, R[4]);
         if (h_out) { h_out[0] = H0; h_out[1] = H1; h_out[2] = H2; h_out[3] = H3; h_out[4] = H4; h_out[5] = H5; }
-        // M^-1 with the (u,q)/(v,p) couplings only (6DoF.py:286-299, :428)
-        dy[6] = p->minv[0] * R[0] + p->minv[4] * R[4];
-        dy[7] = p->minv[7] * R[1] + p->minv[9] * R[3];
-        dy[8] = p->minv[14] * R[2];
-        dy[9] = p->minv[19] * R[1] + p->minv[21] * R[3];
-        dy[10] = p->minv[24] * R[0] + p->minv[28] * R[4];
-        dy[11] = p->minv[35] * R[5];
+        mass_solve6<true>(p, R, dy + 6);
     } else {
         // literal dense form of forceModel (6DoF.py:253-404) for arbitrary constants
         const float vel[6] = {u, v, w, pp, q, r};
@@ -294,14 +311,7 @@ __device__ __forceinline__ void dynamics6(PP p, const float* y, const Trig6& t, 
             R[i] = -c1 - c2 - G[i] + h;
             if (h_out) h_out[i] = h;
         }
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            p = launder_after(p, i > 0 ? dy[6 + i - 1] : R[5]);
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < 6; j++) a = fmaf(p->minv[6 * i + j], R[j], a);
-            dy[6 + i] = a;
-        }
+        mass_solve6<false>(p, R, dy + 6);
     }
     if (rhs_out) {
 #pragma unroll
@@ -1193,6 +1203,29 @@ __global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov6_components_kernel(const 
         for (int k = 0; k < 8; k++) hh = fmaf(p->A[8 * a + k], F[k], hh);
         out[5 * a + 0] = -c1; out[5 * a + 1] = -c2; out[5 * a + 2] = -c3; out[5 * a + 3] = G[a]; out[5 * a + 4] = hh;
     }
+}
+
+// acc = solve(M, RHS) for n given right-hand sides through mass_solve6, the device function of the step kernel (mvrl_mass_solve):
+// the reference's own known answer (example_temp.py:19-28) and the columns of M^-1 each flavour really applies are checked through it.
+template <class PP, bool SYM>
+__global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov6_mass_solve_kernel(const Rov6Dev* __restrict__ pg, int64_t n, const float* rhs, float* acc) {
+    const PP p = param_ptr<PP>(pg);
+    const int64_t i = (int64_t)blockIdx.x * MVRL_STEP_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float R[6], a[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) R[k] = rhs[i * 6 + k];
+    mass_solve6<SYM>(p, R, a);
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc[i * 6 + k] = a[k];
+}
+
+hipError_t launch_rov6_mass_solve(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* rhs, float* acc, hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
+    if (baked) hipLaunchKernelGGL((rov6_mass_solve_kernel<const Rov6Baked*, true>), grid, block, 0, stream, p, n, rhs, acc);
+    else if (sym) hipLaunchKernelGGL((rov6_mass_solve_kernel<CP6, true>), grid, block, 0, stream, p, n, rhs, acc);
+    else hipLaunchKernelGGL((rov6_mass_solve_kernel<CP6, false>), grid, block, 0, stream, p, n, rhs, acc);
+    return hipGetLastError();
 }
 
 hipError_t launch_rov6_components(const Rov6Dev* p, int64_t n, const float* angles, const float* vel, const float* rpm_in, float* comp,

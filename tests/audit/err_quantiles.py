@@ -13,7 +13,8 @@ sys.path.insert(0, REPO)
 from marinevehiclereinforcementlearning_amd import _lib, params as P  # noqa: E402
 from oracle import oracle as oracle_mod  # noqa: E402   (a measuring tool, like the tests: not a product path)
 from tests.parity_util import OutlierAudit, SMOOTH_TOL  # noqa: E402
-from tests.test_gpu_parity import random_rov_batch, circ_err  # noqa: E402
+from tests.test_gpu_parity import circ_err  # noqa: E402
+from tests.parity_util import random_rov_batch  # noqa: E402
 
 
 def main():

@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 from .conftest import GOLDEN, golden, max_scaled_err
-from .test_gpu_parity import circ_err, random_rov_batch, rov_init
+from .parity_util import random_rov_batch
+from .test_gpu_parity import circ_err, rov_init
 from marinevehiclereinforcementlearning_amd import _lib, params as P
 from marinevehiclereinforcementlearning_amd.synthetic import BASE_DT, synthetic_spod
 

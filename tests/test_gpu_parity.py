@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 from .conftest import GOLDEN, golden, max_scaled_err
-from .parity_util import F32_BOUNDS, OutlierAudit, make_resolver, SMOOTH_TOL_NSUB8
+from .parity_util import (F32_BOUNDS, FUZZ_BOUNDS, FUZZ_MAX_BAD_SHARE, FUZZ_MAX_DRIFT_SHARE, OutlierAudit, fuzz_cases, make_resolver,
+                          random_rov_batch, SMOOTH_TOL_NSUB8)
 from marinevehiclereinforcementlearning_amd import _lib, params as P
 from marinevehiclereinforcementlearning_amd.synthetic import BASE_DT, synthetic_spod
 
@@ -92,16 +93,6 @@ def test_reference_rk4_trajectories(oracle_mod, name, dof, n_sub, mode):
     measured = {"g09_rk4_6dof_faithful_nsub4.npz": 1, "g09_rk4_6dof_faithful_nsub4_x64.npz": 2}.get(name, 0)
     assert audit.bad.sum() <= max(1, 2 * measured), audit.report()
     h.close()
-
-
-def random_rov_batch(dof, n, steps, seed):
-    rng = np.random.default_rng(seed)
-    npos = 3 if dof == 6 else 2
-    path = (rng.random((n, 2 * npos)) - 0.5) * 10.0
-    ang = rng.random((n, dof - npos)) * 2 * np.pi
-    init = np.concatenate([path, ang], axis=1).astype(np.float32)
-    actions = rng.uniform(-1, 1, size=(steps, n, dof)).astype(np.float32)
-    return init, actions
 
 
 @pytest.mark.parametrize("dof,mode,n_sub", [(6, P.CTRL_FAITHFUL, 4), (6, P.CTRL_ZOH, 4), (3, P.CTRL_FAITHFUL, 4),
@@ -457,71 +448,51 @@ def test_rov6_with_turbulence_vs_oracle(oracle_mod, base_flow, where, pos_scale,
         h.close()
 
 
-def test_config_fuzz_vs_oracle(oracle_mod, base_flow):
+FUZZ_SEEDS = [2024, 1, 2, 3, 4, 5, 6, 7, 8]
+
+
+@pytest.mark.parametrize("seed", FUZZ_SEEDS)
+def test_config_fuzz_vs_oracle(oracle_mod, base_flow, seed):
     """Seeded sweep over combinations no other test pins: ragged batch sizes (1, 63, 65, 257, 1000: partial tail waves),
     odd sub-step counts, other dt, fixed set-point x turbulence x controller placement x kernel flavour.  Every case is
-    compared with the fp64 oracle for 8 env steps; tolerance 1e-5 with the usual outlier-lane accounting."""
+    compared with the fp64 oracle for 8 env steps; tolerance 1e-5 with the usual outlier-lane accounting.  All nine seeds are
+    part of the suite (round 3 kept one and called the others exploratory)."""
     from oracle import flow_ref
     base, bdx, bdy = base_flow[:3]
     fd, fdx, fdy, fdt = flow_ref.scale(base, bdx, bdy, BASE_DT, 11., 1., 2.)
     uv = np.ascontiguousarray(fd[..., :2])
-    rng = np.random.default_rng(int(os.environ.get("MVRL_FUZZ_SEED", "2024")))     # other seeds: exploratory runs of the sweep
-    sizes = [1, 63, 65, 257, 1000]
-    flavours = {6: [None, dict(m=12.0, Xuu=-19.0), dict(CG=[0.01, -0.015, 0.04], Yr=-0.3)],
-                3: [None, dict(m=12.0, CG=[0.01, 0.02, 0.02], Yr=-0.2)]}
     report = []
-    for case in range(24):
-        dof = 6 if case % 2 == 0 else 3
-        n = sizes[case % len(sizes)]
-        dt = float(rng.choice([0.1, 0.2]))
-        # h = dt / n_sub stays <= 0.1 s: at h = 0.2 the closed loop is outside RK4's stability region (DESIGN.md 1) and
-        # amplifies the fp32 round-off of ANY implementation, which is not a parity statement
-        n_sub = int(rng.choice([1, 2, 3, 4] if dt == 0.1 else [2, 3, 4, 5]))
-        while dof == 3 and dt / n_sub > 0.05:
-            # the 3-DoF closed loop (yaw inertia 0.28 kg m^2 against the same PID derivative floor) leaves RK4's stability
-            # region earlier than the 6-DoF one: exploratory seeds of this sweep (MVRL_FUZZ_SEED, tools/r3_fuzz.sh) produced yaw
-            # rates of 1e7 rad/s after two steps at h = 0.1 s and NaNs with a fixed set-point at h = 0.067 s - in the fp64
-            # oracle as much as on the GPU (a round-2 build of the 3-DoF kernel gave the same numbers).  Not a parity statement.
-            n_sub += 1
-        mode = int(rng.choice([P.CTRL_FAITHFUL, P.CTRL_ZOH]))
-        fixed = bool(rng.integers(0, 2))
-        use_flow = bool(rng.integers(0, 2))
-        over = flavours[dof][int(rng.integers(0, len(flavours[dof])))]
-        kw = {}
-        if over is not None:
-            kw["rov6" if dof == 6 else "rov3"] = (P.rov6_params if dof == 6 else P.rov3_params)(**over)
-        steps = 8
-        init, actions = random_rov_batch(dof, n, steps, 1000 + case)
-        npos = 3 if dof == 6 else 2
-        if use_flow:
-            init[:, :2] *= 0.05                          # keep the vehicles inside the table
-            init[:, npos:npos + 2] *= 0.05
-        cfg = P.make_config("rov6" if dof == 6 else "rov3", n, dt=dt, n_substeps=n_sub, control_mode=mode,
+    for c in fuzz_cases(seed):
+        case, dof, n, fixed, use_flow, kw, steps = c["case"], c["dof"], c["n"], c["fixed"], c["use_flow"], c["kw"], c["steps"]
+        init, actions, toff = c["init"], c["actions"], c["toff"]
+        cfg = P.make_config("rov6" if dof == 6 else "rov3", n, dt=c["dt"], n_substeps=c["n_sub"], control_mode=c["mode"],
                             fixed_setpoint=fixed, auto_reset=False, max_steps=10 ** 9, use_flow=use_flow, **kw)
         h = _lib.Handle(cfg)
         if use_flow:
             h.set_flow(uv.astype(np.float32), fdt, fdx, fdy)
         h.reset(init=init)
-        toff = (rng.random(n) * 2.0).astype(np.float32)
         st = h.get_state()
         st[-2] = toff
         h.set_state(st)
-        env = oracle_mod.OracleRovEnv(dof, n, "f64", dt=dt, n_substeps=n_sub, control_mode=mode, fixed_setpoint=fixed,
+        env = oracle_mod.OracleRovEnv(dof, n, "f64", dt=c["dt"], n_substeps=c["n_sub"], control_mode=c["mode"], fixed_setpoint=fixed,
                                       max_steps=10 ** 9, flow=oracle_mod.FlowTable(uv, fdt, fdx, fdy) if use_flow else None,
                                       **kw)
         env.reset(init.astype(np.float64), toffset=toff)
+        # the SAME C restatement compiled with REAL=float: what any straight fp32 evaluation of the reference's formulation does
+        # on this case.  It is the yardstick for envs that drift: fixed set-points with arbitrary target attitude keep half of the
+        # vehicles pitched beyond 60 deg and tumbling at 1-2 rad/s with the PID in its linear range, where one ulp of an angle near
+        # 2 pi (4.8e-7) x K_D / h x Minv x h = 19 is already 9e-6 rad/s per sub-step (tests/audit/fuzz_isolate.py, DESIGN.md 4).
+        low = oracle_mod.OracleRovEnv(dof, n, "f32", dt=c["dt"], n_substeps=c["n_sub"], control_mode=c["mode"], fixed_setpoint=fixed,
+                                      max_steps=10 ** 9, flow=oracle_mod.FlowTable(uv, fdt, fdx, fdy) if use_flow else None, **kw)
+        low.reset(init.astype(np.float64), toffset=toff)
         ang = [3, 4, 5] if dof == 6 else [2]
-        # Fixed set-points with arbitrary target pitch send vehicles towards +-90 deg: the attitude kinematics divide by
-        # cos(theta) (resources.py:116-132), and past 60 deg they multiply rounding several-fold per sub-step (with ZOH control
-        # at h = 0.1 s errors of 1e-4 were seen at cos(theta) = 0.16 .. 0.41, and a drift of 6.6e-5 - just past the jump line - at
-        # 0.455).  For this sweep an env pitched beyond 60 deg (1 / cos(theta) > 2) counts as ill-conditioned; the sharp bound (0.05)
-        # stays in force in the random-action batches above.
-        bounds = np.array(F32_BOUNDS, float)
-        bounds[4] = 0.5
-        audit = OutlierAudit(n, TOL, bounds=bounds, dof=dof)
+        audit = OutlierAudit(n, TOL, bounds=FUZZ_BOUNDS, dof=dof)
+        audit32 = OutlierAudit(n, TOL, bounds=FUZZ_BOUNDS, dof=dof)
         med = 0.0
         for k in range(steps):
             o_ref, _, _ = env.step(actions[k].astype(np.float64))
+            low.step(actions[k])
+            audit32.update(circ_err(low.y, env.y, ang).max(axis=1), env.margins)
             o_gpu, _, _ = h.step(None if fixed else actions[k])
             e = circ_err(h.get_state()[: 2 * dof].T, env.y, ang).max(axis=1)
             audit.update(e, env.margins)
@@ -530,11 +501,14 @@ def test_config_fuzz_vs_oracle(oracle_mod, base_flow):
             if good.any():
                 assert max_scaled_err(o_gpu[good], o_ref[good]) < 2 * TOL, (case, k)
         bad = audit.bad
-        report.append((case, dof, n, n_sub, dt, mode, fixed, use_flow, h.variant, int(bad.sum()), med))
-        # every env that jumped did so next to a discontinuity; envs that merely drifted past 1e-5 in 8 steps: none expected
-        print("fuzz case %2d dof %d n %4d n_sub %d dt %.1f mode %d fixed %d flow %d %-28s: " % report[-1][:9] + audit.report())
-        audit.assert_explained(max_smooth_share=max(1.0 / n, 0.01))
-        assert bad.sum() <= max(1, int(0.015 * n)), (report[-1], audit.report())
+        report.append((case, dof, n, c["n_sub"], c["dt"], c["mode"], fixed, use_flow, h.variant, int(bad.sum()), med))
+        bad32, drift32 = int(audit32.bad.sum()), int(audit32.smooth().sum())
+        print("fuzz seed %d case %2d dof %d n %4d n_sub %d dt %.1f mode %d fixed %d flow %d %-28s: " % ((seed,) + report[-1][:9]) + audit.report()
+              + f"\n   fp32 build of the oracle on the same case: {bad32} beyond tol, {drift32} drifted")
+        # every env that jumped did so next to a discontinuity; envs that merely drifted past 1e-5 in 8 steps are bounded in number:
+        # 1 % of the batch, or - where the case is ill-conditioned for fp32 as such - what the fp32 oracle build drifts (+25 % + 1)
+        audit.assert_explained(max_smooth_share=max(1.0 / n, FUZZ_MAX_DRIFT_SHARE, (1.25 * drift32 + 1) / n))
+        assert bad.sum() <= max(1, int(FUZZ_MAX_BAD_SHARE * n), int(1.25 * bad32 + 1)), (report[-1], audit.report())
         assert med < 3e-6, report[-1]
         h.close()
     for r in report:
