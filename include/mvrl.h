@@ -269,6 +269,12 @@ int mvrl_set_state(mvrl_handle* h, const float* buf, size_t n_elems);
 int mvrl_get_state_f64(mvrl_handle* h, double* buf, size_t n_elems);
 int mvrl_set_state_f64(mvrl_handle* h, const double* buf, size_t n_elems);
 
+/* obs[n_envs, obs_dim] = dataToState of every env's CURRENT state (6DoF.py:467-483, 3DoF.py:397-409, verySimpleAuv.py:147-214 with
+ * the stored herr_o / perr_o; scripts call it directly: tag/script_4_compareRLandPID.py:100-112), e.g. after mvrl_set_state.
+ * Evaluated by the device function the step and reset kernels use; the state is not modified. */
+int mvrl_observe(mvrl_handle* h, float* obs);
+int mvrl_observe_f64(mvrl_handle* h, double* obs);
+
 /* ---- one evaluation of the vehicle's derivs(t, y) for n independent tuples (unit-level parity, system identification):
  * BlueROV2Heavy6DoF.derivs 6DoF.py:406-442 (PID :43-73 -> allocateThrust :220 -> thrusterModel/limit -> forceModel
  * :253-404 -> solve :428 -> J :430) / BlueROV2Heavy3DoF.derivs 3DoF.py:128-296, with the handle's constants.
@@ -336,6 +342,11 @@ int mvrl_vehicle_ops_f64(mvrl_handle* h, int64_t n, const double* angles, const 
  * (H = A . thrusterModel(limit(rpm))) for n independent tuples; angles[n,3], vel[n,6], rpm_in[n,8]. */
 int mvrl_force_components(mvrl_handle* h, int64_t n, const float* angles, const float* vel, const float* rpm_in, float* comp);
 int mvrl_force_components_f64(mvrl_handle* h, int64_t n, const double* angles, const double* vel, const double* rpm_in, double* comp);
+
+/* acc[n,6] = np.linalg.solve(M, RHS) for n right-hand sides rhs[n,6] (6DoF.py:428; the reference's own known answer is
+ * example_temp.py:19-28), through the constant M^-1 the handle's step kernel applies (10 non-zeros for x_g = y_g = 0, dense otherwise). */
+int mvrl_mass_solve(mvrl_handle* h, int64_t n, const float* rhs, float* acc);
+int mvrl_mass_solve_f64(mvrl_handle* h, int64_t n, const double* rhs, double* acc);
 
 /* Per-step side outputs the reference keeps in timeHistory (6DoF.py:578-587: F0..F5, u0..u7; 3DoF: F0..F2,u0..u3;
  * verySimpleAuv.py:389-403: Fx,Fy,N,u_current,v_current,rmsAc,r0..r4).  Enable BEFORE stepping;

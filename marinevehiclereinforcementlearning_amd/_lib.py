@@ -29,7 +29,7 @@ SYMBOLS = [
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
     "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64", "mvrl_vehicle_ops", "mvrl_vehicle_ops_f64", "mvrl_specialize", "mvrl_jit_compile_check",
-    "mvrl_jit_info", "mvrl_jit_compile_check2", "mvrl_jit_child_env", "mvrl_force_components", "mvrl_force_components_f64",
+    "mvrl_jit_info", "mvrl_jit_compile_check2", "mvrl_jit_child_env", "mvrl_force_components", "mvrl_force_components_f64", "mvrl_mass_solve", "mvrl_mass_solve_f64", "mvrl_observe", "mvrl_observe_f64",
     "mvrl_auv_pd_episodes_dev", "mvrl_rollout_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
@@ -114,6 +114,10 @@ def load(path=None):
     lib.mvrl_vehicle_ops_f64.argtypes = [vp, i64] + [vp] * 8
     lib.mvrl_force_components.argtypes = [vp, i64] + [vp] * 4
     lib.mvrl_force_components_f64.argtypes = [vp, i64] + [vp] * 4
+    lib.mvrl_mass_solve.argtypes = [vp, i64, vp, vp]
+    lib.mvrl_mass_solve_f64.argtypes = [vp, i64, vp, vp]
+    lib.mvrl_observe.argtypes = [vp, vp]
+    lib.mvrl_observe_f64.argtypes = [vp, vp]
     lib.mvrl_rollout_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.mvrl_auv_pd_episodes_dev.argtypes = [vp, vp, vp, C.c_double, i32, vp, vp, vp]
     lib.mvrl_replay_add_sym_dev.argtypes = [i32] + [vp] * 5 + [i64] + [vp] * 6 + [i64, i64, i32, i32, vp]
@@ -315,6 +319,19 @@ class Handle:
         r = np.ascontiguousarray(rpm, self.dtype).reshape(n, 8)
         out = np.zeros((n, 6, 5), self.dtype)
         check(self._fn("mvrl_force_components")(self.h, n, ang.ctypes.data, v.ctypes.data, r.ctypes.data, out.ctypes.data), self.h)
+        return out
+
+    def observe(self):
+        """dataToState of every env's current state (mvrl_observe): [n_envs, obs_dim]."""
+        out = np.zeros((self.n, self.obs_dim), self.dtype)
+        check(self._fn("mvrl_observe")(self.h, out.ctypes.data), self.h)
+        return out
+
+    def mass_solve(self, rhs):
+        """acc = np.linalg.solve(M, RHS) for n right-hand sides through the M^-1 of the handle's step kernel (mvrl_mass_solve)."""
+        r = np.ascontiguousarray(rhs, self.dtype).reshape(-1, 6)
+        out = np.zeros_like(r)
+        check(self._fn("mvrl_mass_solve")(self.h, len(r), r.ctypes.data, out.ctypes.data), self.h)
         return out
 
     def specialize(self):

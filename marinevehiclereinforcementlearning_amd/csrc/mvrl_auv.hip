@@ -473,6 +473,27 @@ hipError_t launch_auv_step(const AuvDev& p, const StepIO& io, const FlowDev& fl,
     return hipGetLastError();
 }
 
+// dataToState(position, heading, velocities) of every env's current state (verySimpleAuv.py:147-214, _cyl.py:100-132) through
+// observe_auv with the stored herr_o / perr_o (mvrl_observe); nothing is modified.
+__global__ __launch_bounds__(MVRL_BLOCK) void auv_observe_kernel(const AuvDev p, const float* state, int64_t n, float* obs) {
+    const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* st = state + i;
+    float tx = 0.f, ty = 0.f, tgt = st[AV_TGT * n];
+    if (p.n_wp > 0) waypoint(p, unpack_int(st[AV_IWP * n]), tx, ty, tgt);
+    float o[11];
+    observe_auv(p, st[AV_X * n], st[AV_Y * n], st[AV_PSI * n], st[AV_VX * n], st[AV_VY * n], st[AV_R * n], tx, ty, tgt,
+                st[AV_HERR_O * n], st[AV_PERR_O * n], st[(AV_PERR_O + 1) * n], o);
+#pragma unroll
+    for (int q = 0; q < 11; q++) obs[i * 11 + q] = o[q];
+}
+
+hipError_t launch_auv_observe(const AuvDev& p, const float* state, int64_t n, float* obs, hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    hipLaunchKernelGGL(auv_observe_kernel, grid, block, 0, stream, p, state, n, obs);
+    return hipGetLastError();
+}
+
 hipError_t launch_auv_reset(const AuvDev& p, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
                             uint64_t seed, int64_t env_offset, float t_quarter, hipStream_t stream) {
     dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);

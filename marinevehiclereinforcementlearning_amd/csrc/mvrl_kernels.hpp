@@ -11,9 +11,13 @@ hipError_t launch_rov6_derivs(const Rov6Dev* p, bool baked, bool sym, int64_t n,
                               hipStream_t stream);
 hipError_t launch_rov6_components(const Rov6Dev* p, int64_t n, const float* angles, const float* vel, const float* rpm_in, float* comp,
                                   hipStream_t stream);
+hipError_t launch_rov6_mass_solve(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* rhs, float* acc, hipStream_t stream);
 hipError_t launch_rov6_unit(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* angles, const float* gcf,
                             const float* rpm_in, const float* vel, float* axes, float* rpm_out, float* rhs, float* h_out,
                             hipStream_t stream);
+hipError_t launch_rov6_observe(const Rov6Dev* p, const float* state, int64_t n, float* obs, hipStream_t stream);
+hipError_t launch_rov3_observe(const Rov3Dev* p, const float* state, int64_t n, float* obs, hipStream_t stream);
+hipError_t launch_auv_observe(const AuvDev& p, const float* state, int64_t n, float* obs, hipStream_t stream);
 hipError_t launch_rov3_derivs(const Rov3Dev* p, bool baked, int64_t n, const float* t, const float* y, const float* sp, float* eold,
                               float* eint, float* told, const uint8_t* has_old, float* dy, float* aux, hipStream_t stream);
 hipError_t launch_rov6_reset(const Rov6Dev* p_dev, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,

@@ -461,6 +461,30 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_reset_kernel(const Rov3Dev* _
     }
 }
 
+// dataToState(systemState) of every env's current state (3DoF.py:397-409) through observe3 (mvrl_observe); nothing is modified.
+__global__ __launch_bounds__(MVRL_BLOCK) void rov3_observe_kernel(const Rov3Dev* __restrict__ pg, const float* state, int64_t n, float* obs) {
+    const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const CP3 p = as_const(pg);
+    const float* st = state + i;
+    float y[6], path[4], sp[3], o[5];
+#pragma unroll
+    for (int q = 0; q < 6; q++) y[q] = st[(R3_Y + q) * n];
+#pragma unroll
+    for (int q = 0; q < 4; q++) path[q] = st[(R3_PATH + q) * n];
+#pragma unroll
+    for (int q = 0; q < 3; q++) sp[q] = st[(R3_SP + q) * n];
+    observe3(p, y, path, sp, o);
+#pragma unroll
+    for (int q = 0; q < 5; q++) obs[i * 5 + q] = o[q];
+}
+
+hipError_t launch_rov3_observe(const Rov3Dev* p, const float* state, int64_t n, float* obs, hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    hipLaunchKernelGGL(rov3_observe_kernel, grid, block, 0, stream, p, state, n, obs);
+    return hipGetLastError();
+}
+
 // One evaluation of vehicle.derivs(t, y) for n independent tuples (see rov6_derivs_kernel)
 template <class PP>
 __global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov3_derivs_kernel(const Rov3Dev* __restrict__ pg, int64_t n, const float* t,

@@ -16,6 +16,10 @@
 #include "mvrl_rk45.hpp"
 #endif
 
+#ifndef MVRL_STORE_SC1   /* experiment (tools/variants.py sc1*): bit 0 state planes, bit 1 observations stored write-through */
+#define MVRL_STORE_SC1 0
+#endif
+
 namespace mvrl {
 
 struct Trig6 {
@@ -193,7 +197,7 @@ __device__ __forceinline__ void allocate6(PP p, const Axes& a, const float* u, f
 // np.linalg.solve(M, RHS) (6DoF.py:428) with the constant M^-1 the host inverted in fp64 (params.py).
 // SYM: x_g = y_g = 0 and diagonal inertia leave only the (u,q) / (v,p) couplings (6DoF.py:286-299): 10 non-zeros.
 template <bool SYM, class PP>
-__device__ __forceinline__ void mass_solve6(PP p, const float* R, float* acc) {
+__device__ __forceinline__ void mass_solve6(PP p, float* R, float* acc) {
     if (SYM) {
         acc[0] = p->minv[0] * R[0] + p->minv[4] * R[4];
         acc[1] = p->minv[7] * R[1] + p->minv[9] * R[3];
@@ -986,18 +990,31 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
         istep = 0;
         observe6(p, y, path, sp, o);
     }
+#if (MVRL_STORE_SC1 & 2)
+#pragma unroll
+    for (int q = 0; q < 9; q++) __hip_atomic_store(&obs_k[(size_t)i * 9 + q], o[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
 #pragma unroll
     for (int q = 0; q < 9; q++) obs_k[(size_t)i * 9 + q] = o[q];
+#endif
     if (!MULTI || kstep == k_steps - 1) {
+        // STW: the state planes' final stores (coalesced 256-B rows per wave); MVRL_STORE_SC1 bit 0 makes them write-through
+        // (`sc1`: the line leaves the XCD's L2 at once instead of waiting, dirty, for the end-of-kernel write-back)
+#if (MVRL_STORE_SC1 & 1)
+#define STW(k, v) __hip_atomic_store(&ST(k), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define STW(k, v) ST(k) = (v)
+#endif
 #pragma unroll
-        for (int k = 0; k < 12; k++) ST(R6_Y + k) = y[k];
+        for (int k = 0; k < 12; k++) STW(R6_Y + k, y[k]);
 #pragma unroll
-        for (int k = 0; k < 6; k++) { ST(R6_EOLD + k) = pid.eold[k]; ST(R6_EINT + k) = pid.eint[k]; }
+        for (int k = 0; k < 6; k++) { STW(R6_EOLD + k, pid.eold[k]); STW(R6_EINT + k, pid.eint[k]); }
         if (!FIXED) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) ST(R6_SP + k) = sp[k];
+            for (int k = 0; k < 6; k++) STW(R6_SP + k, sp[k]);
         }
-        ST(R6_ISTEP) = pack_int(istep);
+        STW(R6_ISTEP, pack_int(istep));
+#undef STW
     }
 #ifdef MVRL_STAMP_ON
     STAMP(3);
@@ -1065,6 +1082,29 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_reset_kernel(const Rov6Dev* _
 #pragma unroll
         for (int q = 0; q < 9; q++) obs[i * 9 + q] = o[q];
     }
+}
+
+// dataToState(systemState) of every env's CURRENT state (6DoF.py:467-483) through observe6, the step kernel's device function
+// (mvrl_observe): the stored way-points / set-point / pose, no state is modified.
+__global__ __launch_bounds__(MVRL_BLOCK) void rov6_observe_kernel(const Rov6Dev* __restrict__ pg, const float* state, int64_t n, float* obs) {
+    const int64_t i = (int64_t)blockIdx.x * MVRL_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const CP6 p = as_const(pg);
+    const float* st = state + i;
+    float y[12], path[6], sp[6], o[9];
+#pragma unroll
+    for (int q = 0; q < 12; q++) y[q] = st[(R6_Y + q) * n];
+#pragma unroll
+    for (int q = 0; q < 6; q++) { path[q] = st[(R6_PATH + q) * n]; sp[q] = st[(R6_SP + q) * n]; }
+    observe6(p, y, path, sp, o);
+#pragma unroll
+    for (int q = 0; q < 9; q++) obs[i * 9 + q] = o[q];
+}
+
+hipError_t launch_rov6_observe(const Rov6Dev* p, const float* state, int64_t n, float* obs, hipStream_t stream) {
+    dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
+    hipLaunchKernelGGL(rov6_observe_kernel, grid, block, 0, stream, p, state, n, obs);
+    return hipGetLastError();
 }
 
 // One evaluation of vehicle.derivs(t, y) for n independent (state, set-point, controller memory) tuples, row-major

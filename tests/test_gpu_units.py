@@ -256,3 +256,114 @@ def test_vehicle_facade_public_methods():
         comp = rov.forceModel(np.zeros(3), g7["angles"][i], g7["vel"][i], g7["rpm"][i], retComp=True)
         assert comp.shape == (6, 5) and max_scaled_err(comp, g7["comp"][i]) < 1e-10
     rov.close()
+
+
+# ---- the vectors the reference itself holds, through HIP (VERDICT r3 "missing 3"): G14, G11, G4 -----------------------------------
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-11), ("f32", 1e-5)])
+@pytest.mark.parametrize("flavour", ["sym", "generic"])
+def test_example_temp_known_answer_through_hip(precision, tol, flavour):
+    """G14 - the one known answer the reference ships (example_temp.py:19-28): acc = np.linalg.solve(M, RHS) with the older
+    CG_z = 0.025.  A handle built with that CG applies ITS M^-1 to the shipped RHS on the device (mvrl_mass_solve -> mass_solve6,
+    the function of the step kernel): the 10-non-zero form (sym) and the dense form (generic: a damping entry of 5e-12 leaves the
+    structured class without moving anything)."""
+    g = golden("g14_example_temp.npz")
+    over = dict(CG=[0., 0., 0.025])
+    if flavour == "generic":
+        over["Yr"] = 5e-12
+    prm = P.rov6_params(**over)
+    assert max_scaled_err(np.array(prm.mass).reshape(6, 6), g["M"]) < 1e-12       # the handle's M is the shipped M
+    h = _lib.Handle(P.make_config("rov6", 1, use_flow=False, precision=precision, rov6=prm))
+    assert flavour in h.variant, h.variant
+    rhs = np.stack([g["RHS"], -2.5 * g["RHS"], np.zeros(6)])
+    acc = h.mass_solve(rhs).astype(np.float64)
+    assert np.max(np.abs(acc[0] - g["acc"])) < 5e-7                                # the file prints 7 significant digits
+    assert max_scaled_err(acc[0], np.linalg.solve(g["M"], g["RHS"])) < tol
+    assert max_scaled_err(acc[1], -2.5 * np.linalg.solve(g["M"], g["RHS"])) < 2.5 * tol and not acc[2].any()
+    h.close()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_constants_the_kernels_apply_match_reference(precision):
+    """G4 - computeThrustAllocation's A and pinv(A) (resources.py:19-35), M and M^-1 (6DoF.py:286-299), 3-DoF pinv (3DoF.py:104-112),
+    READ BACK FUNCTIONALLY from the device: unit inputs through the kernels' own allocate6 / thruster column / mass_solve6 (the
+    default handle is the `baked` flavour, whose constants are compile-time literals - a memory read-back would not see them)."""
+    g = golden("g04_constants.npz")
+    f64 = precision == "f64"
+    tol = 1e-12 if f64 else 2e-6
+    h = handle(6, precision)
+    assert "baked" in h.variant
+    kt = float(g["Kt"])
+    k = 1000.0 * 0.1 ** 4 * kt                                                     # rho D^4 Kt: F = k (rpm / 60)^2
+    # M^-1 column j = solve(M, e_j); M = inv of what came back
+    minv = h.mass_solve(np.eye(6)).astype(np.float64).T
+    assert max_scaled_err(minv, g["Minv6"]) < tol
+    assert max_scaled_err(np.linalg.inv(minv), g["M6"]) < (1e-11 if f64 else 1e-5)
+    # A column k = thruster column H of one thruster at 3000 rpm / its force (inside the limits, above the dead-band)
+    rpm = 3000.0 * np.eye(8)
+    H = h.vehicle_ops(np.zeros((8, 3)), rpm=rpm, want=("thruster_h",))["thruster_h"].astype(np.float64)
+    assert max_scaled_err(H.T / (k * 50.0 ** 2), g["A6"]) < tol
+    # pinv(A) column j = allocation of a unit demand along axis j (level attitude: body axes = global axes), rpm -> force
+    out = h.vehicle_ops(np.zeros((6, 3)), gcf=10.0 * np.eye(6), want=("rpm",))["rpm"].astype(np.float64)
+    cv = np.sign(out) * k * (out / 60.0) ** 2
+    assert max_scaled_err(cv.T / 10.0, g["Ainv6"]) < (1e-11 if f64 else 5e-6)
+    h.close()
+    # 3-DoF: first PID call (dedt = 0, eInt = 0 -> u = K_P e = 20 e) at psi = 0, rpm = inverse thrust curve of pinv(A3) u
+    h3 = handle(3, precision)
+    e = np.eye(3) * 0.5
+    r = h3.derivs(np.zeros(3), np.zeros((3, 6)), e, has_old=np.zeros(3, np.uint8))
+    assert max_scaled_err(r["gcf"], 20.0 * e) < tol * 20
+    rp = r["rpm"].astype(np.float64)
+    cv3 = np.sign(rp) * k * (rp / 60.0) ** 2
+    assert max_scaled_err(cv3.T / 10.0, g["Ainv3"]) < (1e-11 if f64 else 5e-6)
+    h3.close()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("dof", [6, 3])
+def test_data_to_state_golden_through_hip(precision, dof):
+    """G11 - dataToState (6DoF.py:467-483, 3DoF.py:397-409) for 128 random (path, set-point, systemState) triples: way-points through
+    mvrl_reset(init), pose and set-point through mvrl_set_state, the observation through mvrl_observe (observe6 / observe3, the
+    device functions of the step and reset kernels).  fp32: 1e-5, except rows where the yaw / attitude error sits within fp32
+    rounding of the +-pi branch, which flips a clipped observation between -1 and +1 (counted, at most 1 %)."""
+    g = golden("g11_data_to_state.npz")
+    npos = 3 if dof == 6 else 2
+    path, sp, y, ref = g[f"path{dof}"], g[f"sp{dof}"], g[f"state{dof}"], g[f"obs{dof}"]
+    n = len(ref)
+    h = _lib.Handle(P.make_config("rov6" if dof == 6 else "rov3", n, use_flow=False, precision=precision, auto_reset=False))
+    h.reset(init=np.concatenate([path.reshape(n, 2 * npos), sp[:, npos:]], axis=1))
+    st = h.get_state()
+    st[:2 * dof] = y.T
+    st[4 * dof:5 * dof] = sp.T                      # planes: y[2 dof] eOld[dof] eInt[dof] setPoint[dof] path[2 npos] ... (include/mvrl.h)
+    h.set_state(st)
+    obs = h.observe().astype(np.float64)
+    d = np.abs(obs - ref)
+    if precision == "f64":
+        assert d.max() < 1e-12
+    else:
+        from marinevehiclereinforcementlearning_amd.hostmath import angle_error
+        near_branch = np.zeros(n, bool)
+        for i in range(n):
+            for kk in range(dof - npos):
+                near_branch[i] |= np.pi - abs(angle_error(sp[i, npos + kk], y[i, npos + kk])) < 1e-5
+        assert d[~near_branch].max() < 1e-5 and near_branch.sum() <= max(1, n // 100)
+    # a reset observation is the same function of a zero state
+    o0 = h.reset(init=np.concatenate([path.reshape(n, 2 * npos), sp[:, npos:]], axis=1))
+    assert np.array_equal(o0, h.observe())
+    h.close()
+
+
+def test_observe_auv_matches_reset_and_step_observations():
+    """mvrl_observe for AuvEnv: a second dataToState call on the pose a step left behind - the error terms and velocities equal the
+    step's own observation; the increments (columns 3-5: herr - herr_o, perr - perr_o) are zero, because the step stored this
+    pose's errors as the "old" ones (verySimpleAuv.py:349-350)."""
+    n = 257
+    h = _lib.Handle(P.make_config("auv", n, use_flow=False, auto_reset=False, seed=3))
+    o = h.reset()
+    assert np.array_equal(o, h.observe())
+    rng = np.random.default_rng(1)
+    keep = [0, 1, 2, 6, 7, 8, 9, 10]
+    for _ in range(5):
+        o, _, _ = h.step(rng.uniform(-1, 1, (n, 3)).astype(np.float32))
+        o2 = h.observe()
+        assert np.array_equal(o[:, keep], o2[:, keep]) and not o2[:, 3:6].any()
+    h.close()

@@ -39,6 +39,8 @@ VARIANTS = {
     "novote": dict(extra=["-DMVRL_NO_WINDUP_VOTE"], drop=()),         # per-axis wind-up compare-and-select at every PID call (round-2 behaviour)
     "noyaw": dict(extra=["-DMVRL_NO_YAW_INC"], drop=()),              # fresh angle reduction of the yaw error at every PID call (round-2 behaviour)
     "nofb": dict(extra=["-DMVRL_TRIG_NO_FALLBACK"], drop=()),         # attribution only: no full sincos for lanes with large angle increments
+    "sc1st": dict(extra=["-DMVRL_STORE_SC1=1"], drop=()),              # state planes stored write-through (sc1): nothing dirty in L2 at the kernel boundary
+    "sc1all": dict(extra=["-DMVRL_STORE_SC1=3"], drop=()),             # ... and the observations
     "ilp": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp"], drop=()),
     "bias0": dict(extra=["-mllvm", "-amdgpu-schedule-metric-bias=0"], drop=()),
     "ilpw3": dict(extra=["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-DMVRL_MIN_WAVES=3"], drop=()),
