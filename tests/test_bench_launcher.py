@@ -40,6 +40,38 @@ def test_ranks_get_the_torchrun_environment_and_the_worst_exit_code_wins(tmp_pat
     assert "rank 1 1 3 127.0.0.1 True" in r.stderr and "rank 2 2 3 127.0.0.1 True" in r.stderr
 
 
+def test_eight_ranks_rendezvous_and_the_line_reports_all_of_them(tmp_path):
+    """bench.py's own launcher at the world size of BASELINE configs[4]: self_launch(8) starts eight ranks; each joins the process group the
+    way bench.py does (distributed.init_from_env - gloo here, there is no GPU) and takes part in rccl_info, the collective whose result
+    rides in the bench line as `rccl`; rank 0's line must report world_size_seen == 8 and eight device entries."""
+    import json
+    prog = tmp_path / "world8_probe.py"
+    prog.write_text(
+        "import os, sys, json, importlib.util\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        f"spec = importlib.util.spec_from_file_location('bench', {os.path.join(REPO, 'bench.py')!r})\n"
+        "bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)\n"
+        "if 'WORLD_SIZE' not in os.environ:\n"
+        "    bench.__file__ = os.path.abspath(__file__)\n"
+        "    sys.exit(bench.self_launch(8, argv=[]))\n"
+        "import torch.distributed as dist\n"
+        "from marinevehiclereinforcementlearning_amd import distributed as D\n"
+        "rank, world, local_rank = D.init_from_env('gloo')\n"
+        "off, cnt = D.shard_range(8388608, rank, world)\n"
+        "info = D.rccl_info('gloo', local_rank)\n"
+        "dist.barrier()\n"
+        "if rank == 0:\n"
+        "    print(json.dumps({'n_gpus': world, 'rccl': info, 'shard0': [off, cnt]}), flush=True)\n"
+        "dist.destroy_process_group()\n")
+    r = subprocess.run([sys.executable, str(prog)], capture_output=True, text=True, env=_env(), timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # ONE JSON line, rank 0's
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["rccl"]["world_size_seen"] == 8 and len(j["rccl"]["devices"]) == 8 and j["rccl"]["backend"] == "gloo"
+    assert j["shard0"] == [0, 1048576]                                 # configs[4]: 8 388 608 envs = 8 x 1 048 576
+
+
 def test_a_dead_rank_takes_the_hung_ones_with_it(tmp_path):
     """A rank that dies while the others wait for it (a broken rendezvous) must not hang the job: the launcher kills the survivors
     after its grace period and reports the failure."""

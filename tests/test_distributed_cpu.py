@@ -78,7 +78,7 @@ def run_world(n_global, mode, world=2, inplace=False, scatter=False):
     procs = [ctx.Process(target=worker, args=(r, world, port, n_global, mode, q, inplace, scatter)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world if mode == "all" else 1)]
+    res = [q.get(timeout=300) for _ in range(world if mode == "all" else 1)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -124,6 +124,23 @@ def test_two_rank_scatter_step_gather_equals_single_process(n_global):
     for s in range(4):
         for j in range(2):
             assert np.array_equal(got[s][j], ref[s][j])
+
+
+@pytest.mark.parametrize("n_global,mode,scatter", [(67, "root", False), (67, "all", False), (13, "root", True)])
+def test_eight_rank_gather_equals_single_process(n_global, mode, scatter):
+    """World size 8 - the size of BASELINE configs[4] and half of the reference's SubprocVecEnv pool (tag/main_00_sbl.py:145, nProc 16) -
+    with ragged shards (67 = 3 x 9 + 5 x 8; 13 = 5 x 2 + 3 x 1): shard ranges, padded gather message, scatter of the actions from rank 0,
+    concatenation == the unsharded batch bit for bit on rank 0 (root) / on every rank (all)."""
+    rs = [D.shard_range(n_global, r, 8) for r in range(8)]
+    assert sum(c for _, c in rs) == n_global and max(c for _, c in rs) - min(c for _, c in rs) == 1
+    ref0, ref = single_process(n_global)
+    res = run_world(n_global, mode, world=8, inplace=True, scatter=scatter)
+    assert len(res) == (8 if mode == "all" else 1)
+    for rank, got0, got in res:
+        assert np.array_equal(got0, ref0)
+        for s in range(4):
+            assert np.array_equal(got[s][0], ref[s][0])
+            assert np.array_equal(got[s][2], ref[s][2].astype(np.uint8))
 
 
 def test_scatter_single_process_passthrough():
