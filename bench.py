@@ -8,7 +8,8 @@ One "step" = one env step of every environment of the batch: one launch of the f
 independent, so each chain's next launch only waits for its own previous one and the other chain's kernel covers the
 launch gap, ramp and tail).  Timing: after a stated pre-warm (>= --prewarm-s seconds of the same steps, so that the
 shader clock has settled) and W warm-up steps, the K-step timed region - bracketed by barrier + synchronize - is repeated
---repeats times; `ms_per_step` / `value` are the MEDIAN repeat (max over ranks per repeat), all repeats are in the line.
+--repeats times (default: as many as give each launch plan >= 1 s of timed work, 11 .. 1001); `ms_per_step` / `value` are the
+MEDIAN repeat (max over ranks per repeat); the repeats (or 33 order statistics of them) are in the line.
 `value` is the sharded hot path with outputs left in each rank's HBM (the same thing at every N); for N > 1 the
 RCCL gather of observations/rewards/dones to rank 0 that BASELINE.json's 8-GPU config names is run and timed over the
 same K steps and reported beside it as `with_gather` (root ingest is xGMI-link-bound).  Workloads (BASELINE.json configs):
@@ -170,8 +171,9 @@ def main():
     # run measures 145 us/launch, 2000 steps and more 133 us on the same device)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--repeats", type=int, default=11, help="the K-step timed region is repeated this many times; the median is reported "
-                    "(short regions swing by +-4 % with the power controller's state: see timing.ms_per_step_repeats)")
+    ap.add_argument("--repeats", type=int, default=0, help="the K-step timed region is repeated this many times; the median is reported "
+                    "(short regions swing by +-4 %% with the power controller's state: see timing.ms_per_step_repeats).  0 (default) = as "
+                    "many as make >= 1 s of timed GPU work per launch plan, at least 11, at most 1001: a 20-step region lasts 2 ms")
     ap.add_argument("--prewarm-s", type=float, default=0.4, help="seconds of untimed steps before the warm-up (clock settling)")
     ap.add_argument("--chains", type=int, default=2, help="independent lane-range chains per step (1 = one launch per step on one stream)")
     ap.add_argument("--launch", default="auto", choices=["auto", "chains", "single"],
@@ -425,9 +427,27 @@ def main():
     if stepper is not None:
         plans = {"auto": ["chains", "single"], "chains": ["chains"], "single": ["single"]}[args.launch]
     by_plan = {pl: [] for pl in plans}
-    for r in range(max(1, args.repeats)):
+    n_repeats = args.repeats
+    if n_repeats <= 0:
+        # automatic: the pre-warm measured what a step takes here; repeat the K-step region until each plan has >= 1 s of timed
+        # work behind its median (K = 2000: 11 repeats; the driver's K = 20: ~450 regions of 2.2 ms instead of 11 of them)
+        n_repeats = int(min(1001, max(11, 1.0 / max(1e-9, K * step_us_estimate * 1e-6))))
+        n_repeats += 1 - n_repeats % 2          # odd: the median is a repeat that was measured
+        if world > 1:                           # every rank must run the same number of regions (they contain barriers)
+            t_rep = torch.tensor([n_repeats], dtype=torch.int64, device=dev)
+            dist.all_reduce(t_rep, op=dist.ReduceOp.MAX)
+            n_repeats = int(t_rep.item())
+    for r in range(max(1, n_repeats)):
         for pl in plans:
             by_plan[pl].append(timed_region(pl))
+
+    def repeat_list(vals):
+        """all repeats when they are few; otherwise 33 evenly spaced order statistics (min ... median ... max) - `timing.repeats` says how many there were"""
+        vals = list(vals)
+        if len(vals) <= 33:
+            return vals
+        srt = sorted(vals)
+        return [srt[round(i * (len(srt) - 1) / 32)] for i in range(33)]
 
     def median_of(lst):
         order = sorted(range(len(lst)), key=lambda i: lst[i]["elapsed"])
@@ -463,8 +483,11 @@ def main():
         achieved = wl["bytes"] * n / per_step_s / 1e9
         khash = build.source_hash()
         traffic, traffic_src, valu = None, None, None
-        tp = os.path.join(REPO, "profiles", "r03_counters.json")
-        if os.path.exists(tp):
+        # the newest round's counter summary (profiles/rNN_counters.json, tools/session.sh summarize)
+        import glob as _glob
+        tps = sorted(_glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_counters.json")))
+        tp = tps[-1] if tps else ""
+        if tp:
             try:
                 tj = json.load(open(tp))
                 # a workload at another batch size is profiled under <workload>_<envs> (tools/profile_round.sh ... --envs-per-gpu N)
@@ -473,7 +496,7 @@ def main():
                 if ent and tj.get("kernel_source_hash") == khash and n == ent.get("envs") and args.precision == "f32" \
                         and args.control_mode == "faithful" and args.n_substeps == 4 and not args.rollout:
                     traffic = ent.get("hbm_bytes_per_step")
-                    traffic_src = {"file": "profiles/r03_counters.json", "kernel_source_hash": khash, "commit": tj.get("commit"),
+                    traffic_src = {"file": "profiles/" + os.path.basename(tp), "kernel_source_hash": khash, "commit": tj.get("commit"),
                                    # rocprofv3 --kernel-trace --stats of this command under either launch plan: a chains launch
                                    # (half the batch, two in flight) lasts about one step; a single launch IS one step
                                    "rocprof_kernel_avg_us": {"chains": ent.get("bench_command_kernel_avg_us"),
@@ -496,7 +519,7 @@ def main():
         auv_note = ("HBM-bound kernel; working set of a step (state planes + outputs + one action batch) %.0f MB " % (working_set / 1e6) +
                     ("is of the size of the 256 MB Infinity Cache: part of the plane traffic is served from it, above what HBM streams at - "
                      "`frac` is then a fraction of the HBM peak but not a pure HBM measurement (see the %d-env run in "
-                     "profiles/r03_bench_table.txt)" % 4194304
+                     "the bench table under profiles/)" % 4194304
                      if working_set <= 512e6 else
                      "exceeds the 256 MB Infinity Cache several times over: the plane traffic comes from HBM"))
         launch_desc = ("one launch per 250-step episode batch" if pd_obj is not None else
@@ -514,9 +537,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "launch_plan": plan,
             "timing": {"repeats": len(reps), "statistic": "median repeat of the K-step region (max over ranks per repeat)",
-                       "ms_per_step_repeats": [r_["elapsed"] / K * 1e3 for r_ in reps],
+                       "ms_per_step_repeats": repeat_list(r_["elapsed"] / K * 1e3 for r_ in reps),
+                       "repeats_listed": "all, in order" if len(reps) <= 33 else "33 evenly spaced order statistics of the %d repeats (min .. median .. max)" % len(reps),
                        "launch_plans": {pl: {"ms_per_step": meds[pl]["elapsed"] / K * 1e3,
-                                             "ms_per_step_repeats": [r_["elapsed"] / K * 1e3 for r_ in by_plan[pl]]} for pl in plans},
+                                             "ms_per_step_repeats": repeat_list(r_["elapsed"] / K * 1e3 for r_ in by_plan[pl])} for pl in plans},
                        "prewarm_s": prewarm_s, "prewarm_steps": pre_steps},
             "config": {"workload": wl["name"], "envs_per_gpu": n, "global_envs": world * n, "dt": 0.02 if wl["model"].startswith("auv") else 0.2,
                        "n_substeps": args.n_substeps, "control_mode": args.control_mode, "episode_len": 250,
@@ -574,7 +598,7 @@ def main():
             run_gather(min(max(W, 2), 8))
             sync()
             greps = []
-            for r in range(max(1, args.repeats)):
+            for r in range(max(1, min(n_repeats, 101))):
                 sync()
                 t1 = time.perf_counter()
                 run_gather(K)
@@ -586,7 +610,7 @@ def main():
             ingest = (world - 1) * gather[0].msg_bytes * K / e2 / 1e9     # bytes that cross xGMI into the root
             peak = (world - 1) * XGMI_LINK_GBS
             wg = {"value": world * n * K / e2, "unit": "env-steps/s", "ms_per_step": e2 / K * 1e3, "mode": args.gather,
-                  "ms_per_step_repeats": [g / K * 1e3 for g in greps],
+                  "ms_per_step_repeats": repeat_list(g / K * 1e3 for g in greps),
                   "bytes_per_step_at_root": gather[0].bytes_per_step(),
                   "roofline": {"bound": "xgmi-ingest", "achieved": ingest, "peak": peak, "unit": "GB/s", "frac": ingest / peak,
                                "note": "bytes entering the root GPU per second against (N-1) links x 76.8 GB/s per direction"},

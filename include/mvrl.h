@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MVRL_ABI_VERSION 2
+#define MVRL_ABI_VERSION 3
 
 /* ---- models (which reference environment the handle replaces) ------------------------------ */
 #define MVRL_MODEL_AUV 0  /* AuvEnv, explicit Euler + turbulence current   tag/verySimpleAuv.py:76-416 */
@@ -260,6 +260,11 @@ int mvrl_get_terminal_obs_dev(mvrl_handle* h, void* obs_dev, void* stream);
  *   AUV  (56): pose[6] headingTarget herr_o perr_o[2] mult[11] flowTimeOffset actionRing[30] iStep iWp episode ringPhase
  *              (the action of step iStep sits in ring slot (iStep - 1 + ringPhase) % 10: a new episode's ring continues
  *              at the slot where the previous one stopped, so the envs of a wave keep writing one plane per step)
+ * BINARY ANGLES (ABI 3): in an fp32 handle the Euler-angle words of the rigid-body models - y[3..5] (phi, theta, psi) of ROV6, y[2] (psi)
+ * of ROV3 - are uint32 bit patterns b with angle = b * 2 pi / 2^32 in [0, 2 pi): the reference wraps its angles into that interval
+ * (6DoF.py:560, 3DoF.py:480), where an fp32 NUMBER is only resolved to 4.8e-7 rad; the binary angle resolves 1.5e-9 rad everywhere,
+ * wraps exactly (integer overflow) and lets a step ADD its small increment.  Encode: b = llrint(fmod(angle, 2 pi) *
+ * 2^32 / (2 pi)) mod 2^32; decode: (double)b * 2 pi / 2^32.  fp64 handles keep plain doubles in [0, 2 pi).  AuvEnv is unchanged.
  * iStep / iWp / episode are integer bit patterns (int32 in a float slot / int64 in a double slot).  `episode` counts
  * the env's resets and is the counter of its Philox stream: random resets depend on (seed, global env id, episode)
  * only, not on how many launches the handle has issued - restoring a state restores the RNG position, and a sequence

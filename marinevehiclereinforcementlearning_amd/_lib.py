@@ -247,13 +247,39 @@ class Handle:
         check(self._fn("mvrl_get_terminal_obs")(self.h, out.ctypes.data), self.h)
         return out
 
-    def get_state(self):
+    def get_state(self, raw=False):
+        """The SoA state planes [state_words, n_envs] (include/mvrl.h).  An fp32 handle keeps the Euler angles of the rigid-body
+        models as binary angles (uint32 bit patterns); by default they are handed out DECODED - fp32 radians in [0, 2 pi), the
+        reference's convention (6DoF.py:560) - and `set_state` encodes them again.  Angle entries that come back to `set_state`
+        unchanged are restored bit for bit (the raw planes of the last `get_state` are remembered), so get -> edit other planes ->
+        set is an exact round trip.  raw=True: the planes verbatim, as the C ABI exchanges them."""
         buf = np.zeros((self.state_words, self.n), self.dtype)
         check(self._fn("mvrl_get_state")(self.h, buf.ctypes.data, buf.size), self.h)
+        planes = () if self.f64 else P.ANGLE_PLANES[self.model]
+        if raw or not planes:
+            return buf
+        idx = list(planes)
+        bits = buf[idx].view(np.uint32).copy()
+        dec = (bits.astype(np.float64) * (2.0 * np.pi / 4294967296.0)).astype(np.float32)
+        dec[dec >= np.float32(2.0 * np.pi)] = 0.0          # 2 pi - 1e-9 rounds up to fp32(2 pi): that is the angle 0
+        buf[idx] = dec
+        self._angle_cache = (dec.copy(), bits)
         return buf
 
-    def set_state(self, buf):
+    def set_state(self, buf, raw=False):
         b = _real(buf, self.dtype, (self.state_words, self.n))
+        planes = () if self.f64 else P.ANGLE_PLANES[self.model]
+        if planes and not raw:
+            b = b.copy()
+            idx = list(planes)
+            ang = b[idx]
+            bits = np.round(np.mod(ang.astype(np.float64), 2.0 * np.pi) * (4294967296.0 / (2.0 * np.pi))).astype(np.uint64)
+            bits = (bits & 0xFFFFFFFF).astype(np.uint32)
+            cache = getattr(self, "_angle_cache", None)
+            if cache is not None and cache[0].shape == ang.shape:
+                same = ang == cache[0]
+                bits[same] = cache[1][same]
+            b[idx] = bits.view(np.float32)
         check(self._fn("mvrl_set_state")(self.h, b.ctypes.data, b.size), self.h)
 
     def step_counter(self, state=None):

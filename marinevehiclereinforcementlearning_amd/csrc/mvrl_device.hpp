@@ -127,6 +127,66 @@ __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
 #endif
 }
 
+// ---- binary angles (fp32 build; DESIGN.md section 2 "Euler angles as binary angles") ---------------------------------------
+// The reference keeps its Euler angles wrapped to [0, 2 pi) (6DoF.py:560, 3DoF.py:480).  As an fp32 number such an angle is resolved to
+// 4.8e-7 rad near 2 pi - and on a whole 250-step episode that storage rounding, re-injected every step, is what separates an fp32
+// trajectory from the fp64 one (tests/audit/episode_audit.py: of the envs that an fp64 computation with fp32 state storage loses, 95 % are
+// lost to the three angle words).  The state planes of the fp32 build therefore hold the angles as 32-bit BINARY ANGLES: angle = b * 2 pi / 2^32, uniform
+// resolution 1.5e-9 rad, the wrap is integer overflow (exact), a step ADDS its small increment, and the one full sincos of a step reduces
+// its argument exactly (top two bits = quadrant).  Same 4 bytes per angle; mvrl_get_state hands out the bit patterns like iStep's.
+#if !MVRL_F64
+#define MVRL_BAM 1
+#define MVRL_BAM_RAD 1.4629180792671596e-9f      /* 2 pi / 2^32, rounded to fp32 ...                                  */
+#define MVRL_BAM_RAD_LO (-4.0709404e-17f)        /* ... and the rest of it: 2 pi / 2^32 minus that fp32 number            */
+#define MVRL_RAD_BAM 683565275.57643159f         /* 2^32 / (2 pi) */
+// signed value in [-pi, pi) as ONE fp32 number (two roundings, <= 2.4e-7): where an absolute angle of ordinary fp32 quality is enough
+// (the step kernels pass the conversion factors in: a value they pinned to a register next to its uses, so that LLVM does not hoist a
+// dozen literals out of the fused-launch loop and keep them in VGPRs across the whole RK4 loop)
+__device__ __forceinline__ float bam_to_rad(uint32_t b, float c_rad = MVRL_BAM_RAD) { return (float)(int32_t)b * c_rad; }
+// the same angle in the reference's convention [0, 2 pi) (set-point = a * scale + angle is reported that way; 6DoF.py:545-552)
+__device__ __forceinline__ float bam_to_rad_pos(uint32_t b, float c_rad = MVRL_BAM_RAD) { const float a = bam_to_rad(b, c_rad); return (a < 0.f) ? a + MVRL_TWO_PI_HI : a; }
+// signed value as hi + lo (|lo| <~ 1e-7, the pair exact to ~1e-11): top 24 bits through an exact product error, low 8 bits on top
+__device__ __forceinline__ void bam_to_rad2(uint32_t b, float& hi, float& lo) {
+    const float th = (float)((int32_t)b >> 8);                  // exact: 24 significant bits
+    const float tl = (float)(b & 0xffu);
+    const float k_hi = 256.0f * MVRL_BAM_RAD, k_lo = 256.0f * MVRL_BAM_RAD_LO;
+    hi = th * k_hi;
+    asm("" : "+v"(hi));   // -ffast-math must not see fma(th, k_hi, -(th * k_hi)) as zero: it is the product's rounding error
+    lo = fmaf(tl, MVRL_BAM_RAD, fmaf(th, k_lo, fmaf(th, k_hi, -hi)));
+}
+// b + (angle increment d [rad]); the wrap to [0, 2 pi) of 6DoF.py:560 is the integer overflow.  |d| of any size: reduced first.
+__device__ __forceinline__ uint32_t bam_add(uint32_t b, float d, float c_bam = MVRL_RAD_BAM) {
+    d = fmaf(-rintf(d * MVRL_INV_TWO_PI), MVRL_TWO_PI_HI, d);   // |d| <= pi (1 + 1e-7): d * 2^32 / (2 pi) is within 2^31 (1 + 1e-7) ...
+    // ... where gfx950's v_cvt_i32_f32 saturates: a half turn comes out 1.5e-9 rad short at worst
+    return b + (uint32_t)(int32_t)rintf(d * c_bam);
+}
+__device__ __forceinline__ uint32_t rad_to_bam(float a) { return bam_add(0u, a); }
+// sin and cos of a binary angle: the top two bits (after rounding to the nearest quadrant) ARE the Cody-Waite quotient, the remainder is
+// exact, and its conversion to radians carries its rounding error along (first-order correction): ~1 ulp of the RESULT for any angle
+__device__ __forceinline__ void sincos_bam(uint32_t b, float& s, float& c, float c_rad = MVRL_BAM_RAD) {
+    const uint32_t k = (b + 0x20000000u) >> 30;                 // nearest multiple of pi/2 (4 wraps to 0 with b)
+    const int32_t rem = (int32_t)(b - (k << 30));               // [-2^29, 2^29)
+    const int32_t rh = rem & ~0x3f;                             // 24 significant bits: exact as fp32
+    const float fh = (float)rh, fl = (float)(rem - rh);
+    float r = fh * c_rad;
+    asm("" : "+v"(r));    // as in bam_to_rad2: the next line's innermost fma is the rounding error of this product
+    const float lo = fmaf(fl, c_rad, fmaf(fh, MVRL_BAM_RAD_LO, fmaf(fh, c_rad, -r)));
+    const float r2 = r * r;
+    const float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    float sn = fmaf(ps * r2, r, r);
+    const float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+    float cn = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    const float sn0 = sn;
+    sn = fmaf(cn, lo, sn);
+    cn = fmaf(-sn0, lo, cn);
+    const float s1 = (k & 1u) ? cn : sn, c1 = (k & 1u) ? sn : cn;
+    s = (k & 2u) ? -s1 : s1;
+    c = ((k + 1u) & 2u) ? -c1 : c1;
+}
+#else
+#define MVRL_BAM 0
+#endif
+
 // the step counter shares the SoA state buffer with the real-valued planes: stored as an integer bit pattern
 #if MVRL_F64
 __device__ __forceinline__ int unpack_int(double v) { return (int)__double_as_longlong(v); }

@@ -163,13 +163,18 @@ __device__ __forceinline__ void derivs3(PP p, const float* y, const Trig1& t, Pi
     dynamics3<FLOW>(p, y, t.c, t.s, F, cur, dy);
 }
 
+// e_psi = angleError(setPoint[2], heading) (3DoF.py:407): the step kernel has it from its error coordinates
 template <class PP>
-__device__ __forceinline__ void observe3(PP p, const float* y, const float* path, const float* sp, float* o) {
+__device__ __forceinline__ void observe3e(PP p, const float* y, const float* path, float e_psi, float* o) {
     o[0] = clampf((path[0] - y[0]) * p->inv_obs_pos, -1.f, 1.f);  // 3DoF.py:397-409
     o[1] = clampf((path[1] - y[1]) * p->inv_obs_pos, -1.f, 1.f);
     o[2] = clampf((path[2] - y[0]) * p->inv_obs_pos, -1.f, 1.f);
     o[3] = clampf((path[3] - y[1]) * p->inv_obs_pos, -1.f, 1.f);
-    o[4] = clampf(angle_error(sp[2], y[2]) * p->inv_obs_ang, -1.f, 1.f);
+    o[4] = clampf(e_psi * p->inv_obs_ang, -1.f, 1.f);
+}
+template <class PP>
+__device__ __forceinline__ void observe3(PP p, const float* y, const float* path, const float* sp, float* o) {
+    observe3e(p, y, path, angle_error(sp[2], y[2]), o);
 }
 
 // 3DoF.py:423-424: path = (rand(4).reshape(2,2) - 0.5) * 10, heading = rand() * 2 pi
@@ -280,14 +285,31 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     // (fixed set-point: z = pose_start - pose, starting at 0, and the controller adds e0 = setPoint - pose_start)
     const bool fixed = io.fixed_sp != 0;
     float z0[3], e0[3], org[3];
+#if MVRL_BAM
+    // the heading plane holds a binary angle (mvrl_device.hpp "binary angles"; y[2] carries its bit pattern, also from one step of a
+    // fused launch to the next): an ordinary fp32 copy for the origin of the rare full-sincos lanes, the bits for everything else
+    const uint32_t bpsi = (uint32_t)unpack_int(y[2]);
+#endif
 #pragma unroll
     for (int k = 0; k < 3; k++) {  // 3DoF.py:469-472
         const float da = spin[k] * p->act_scale[k];
-        sp[k] = fixed ? spin[k] : da + y[k];
-        e0[k] = fixed ? spin[k] - y[k] : da;           // the error at the start of the step (yaw: unwrapped)
-        org[k] = fixed ? y[k] : sp[k];                 // pose = org - z
+#if MVRL_BAM
+        const float yk = (k == 2) ? bam_to_rad(bpsi) : y[k];
+#else
+        const float yk = y[k];
+#endif
+        sp[k] = fixed ? spin[k] : da + yk;
+        e0[k] = fixed ? spin[k] - yk : da;             // the error at the start of the step (yaw: unwrapped)
+        org[k] = fixed ? yk : sp[k];                   // pose = org - z
         z0[k] = fixed ? 0.f : e0[k];
     }
+#if MVRL_BAM
+    if (fixed) {   // the yaw error against a fixed set-point from the binary angle's hi + lo pair (wrapped by the controller)
+        float hi, lo;
+        bam_to_rad2(bpsi, hi, lo);
+        e0[2] = (spin[2] - hi) - lo;
+    }
+#endif
     float2 cur = make_float2(0.f, 0.f);
     if (FLOW) cur = flow_combine(tap);
     if (first) { pid.eold[0] = e0[0]; pid.eold[1] = e0[1]; pid.eold[2] = angle_error(e0[2], 0.f); }
@@ -296,6 +318,10 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     const float h = in_vgpr(h_s), hh = in_vgpr(0.5f * h_s), h6 = in_vgpr(h_s / 6.f), inv_hh = in_vgpr(1.0f / (0.5f * h_s));
     float* const aux_row = io.aux ? io.aux + (size_t)i_in * 7 : nullptr;
     float inc_prev[3] = {0.f, 0.f, 0.f};  // see mvrl_rov6.hip
+#if MVRL_BAM
+    float e_psi = 0.f;
+    uint32_t bpsi_new = 0u;
+#endif
 #if MVRL_F64
     if (INTEG == 1) {  // the reference's own integrator (3DoF.py:475-477), see mvrl_rk45.hpp
         float told = ST(R3_TOLD), time = ST(R3_TIME);
@@ -310,7 +336,12 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     } else
 #endif
     {
+#if MVRL_BAM
+    Trig1 tb;                 // heading at the start of the step: the one full sincos of the step, of the binary angle
+    sincos_bam(bpsi, tb.s, tb.c);
+#else
     Trig1 tb = trig1(y[2]);   // heading at the start of the step: the one full sincos of the step
+#endif
 #pragma unroll
     for (int q = 0; q < 3; q++) y[q] = z0[q];          // from here to the end of the loop y[0..2] is the ERROR setPoint - pose
 #define MVRL_AX3(c_, q_) ((q_) < 3 ? -(c_) : (c_))
@@ -366,10 +397,22 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
         if (!ZOH && ((ks + 1) & 3) != 0 && ks + 1 < io.n_sub) tb = stage_trig1(tb, dpsi, org[2], y[2]);   // base of the next sub-step
     }
 #undef MVRL_AX3
+#if MVRL_BAM
+    // the heading leaves the loop as the error z_end; the step moved it by z_start - z_end, which is ADDED to the binary start angle
+    // (the wrap of 3DoF.py:480 is the integer overflow); the observation's heading error is z_end itself (+ E0 with a fixed set-point)
+    e_psi = angle_error((fixed ? e0[2] : 0.f) + y[2], 0.f);
+    if (!fixed) sp[2] = z0[2] + bam_to_rad_pos(bpsi);                  // 3DoF.py:469-472 with the heading in [0, 2 pi)
+    bpsi_new = bam_add(bpsi, z0[2] - y[2]);
+#pragma unroll
+    for (int q = 0; q < 2; q++) y[q] = org[q] - y[q];   // back to the position
+#else
 #pragma unroll
     for (int q = 0; q < 3; q++) y[q] = org[q] - y[q];   // back to the pose
+#endif
     }
+#if !MVRL_BAM
     y[2] = mod_two_pi(y[2]);  // 3DoF.py:480
+#endif
     // The epilogue addresses the same SoA planes as the prologue.  Left alone, LLVM keeps all ~40 prologue
     // addresses alive in VGPR pairs across the whole RK4 loop (~75 registers, the difference between 2 and 3 waves
     // per SIMD) instead of recomputing them; hiding the lane index behind an empty asm makes it recompute.
@@ -380,7 +423,12 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
 #pragma unroll
     for (int k = 0; k < 4; k++) path[k] = ST(R3_PATH + k);
     float o[5];
+#if MVRL_BAM
+    observe3e(p, y, path, e_psi, o);
+    y[2] = pack_int((int)bpsi_new);      // the heading word is a bit pattern again
+#else
     observe3(p, y, path, sp, o);
+#endif
     const bool done = istep >= io.max_steps;
     reward_k[i] = 0.f;
     done_k[i] = done ? 3 : 0;  // bit 0 = done, bit 1 = time limit
@@ -470,6 +518,9 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov3_observe_kernel(const Rov3Dev*
     float y[6], path[4], sp[3], o[5];
 #pragma unroll
     for (int q = 0; q < 6; q++) y[q] = st[(R3_Y + q) * n];
+#if MVRL_BAM
+    y[2] = bam_to_rad_pos((uint32_t)unpack_int(y[2]));
+#endif
 #pragma unroll
     for (int q = 0; q < 4; q++) path[q] = st[(R3_PATH + q) * n];
 #pragma unroll

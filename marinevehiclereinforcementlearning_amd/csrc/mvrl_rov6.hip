@@ -402,9 +402,20 @@ struct Park12 {
 // = set-point - error, observation) - six registers the right-hand side can use instead.
 struct SpStore {
     volatile float4* base;   // [2][MVRL_STEP_BLOCK]
-    __device__ __forceinline__ void put(const float* sp) const {
-        float4 a, b; a.x = sp[0]; a.y = sp[1]; a.z = sp[2]; a.w = sp[3]; b.x = sp[4]; b.y = sp[5]; b.z = 0.f; b.w = 0.f;
+    // x0, x1: the two spare words of the second float4 (the step's binary start angles ride there, put_extra / get_extra)
+    __device__ __forceinline__ void put(const float* sp, float x0 = 0.f, float x1 = 0.f) const {
+        float4 a, b; a.x = sp[0]; a.y = sp[1]; a.z = sp[2]; a.w = sp[3]; b.x = sp[4]; b.y = sp[5]; b.z = x0; b.w = x1;
         const_cast<float4&>(base[threadIdx.x]) = a;
+        const_cast<float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]) = b;
+        asm volatile("" ::: "memory");
+    }
+    __device__ __forceinline__ void get_extra(float& x0, float& x1) const {
+        asm volatile("" ::: "memory");
+        const float4 b = const_cast<const float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]);
+        x0 = b.z; x1 = b.w;
+    }
+    __device__ __forceinline__ void put_spare(float x0) const {   // only the spare word (the six values are not in use)
+        float4 b; b.x = 0.f; b.y = 0.f; b.z = x0; b.w = 0.f;
         const_cast<float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]) = b;
         asm volatile("" ::: "memory");
     }
@@ -417,9 +428,11 @@ struct SpStore {
 #else
 #define MVRL_STEP_BOUNDS6 MVRL_STEP_BOUNDS
 struct SpStore {   // no parking (fp64 build, MVRL_NO_PARK): the set-point stays in registers
-    float v[6];
-    __device__ __forceinline__ void put(const float* sp) { for (int q = 0; q < 6; q++) v[q] = sp[q]; }
+    float v[6], x[2];
+    __device__ __forceinline__ void put(const float* sp, float x0 = 0.f, float x1 = 0.f) { for (int q = 0; q < 6; q++) v[q] = sp[q]; x[0] = x0; x[1] = x1; }
     __device__ __forceinline__ void get(float* sp) const { for (int q = 0; q < 6; q++) sp[q] = v[q]; }
+    __device__ __forceinline__ void get_extra(float& x0, float& x1) const { x0 = x[0]; x1 = x[1]; }
+    __device__ __forceinline__ void put_spare(float x0) { x[0] = x0; }
 };
 #endif
 
@@ -522,15 +535,21 @@ __device__ __forceinline__ void dynamics_only6(PP p, const float* y, const Trig6
     dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, dy);
 }
 
-// dataToState (6DoF.py:467-483)
+// dataToState (6DoF.py:467-483).  e_ang[3] = angleError(setPoint[3:6], angles) (:479-481): the step kernel has it from its error
+// coordinates, the other callers form it from the two angles (observe6 below)
 template <class PP>
-__device__ __forceinline__ void observe6(PP p, const float* y, const float* path, const float* sp, float* o) {
+__device__ __forceinline__ void observe6e(PP p, const float* y, const float* path, const float* e_ang, float* o) {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         o[k] = clampf((path[k] - y[k]) * p->inv_obs_pos, -1.f, 1.f);
         o[3 + k] = clampf((path[3 + k] - y[k]) * p->inv_obs_pos, -1.f, 1.f);
-        o[6 + k] = clampf(angle_error(sp[3 + k], y[3 + k]) * p->inv_obs_ang, -1.f, 1.f);
+        o[6 + k] = clampf(e_ang[k] * p->inv_obs_ang, -1.f, 1.f);
     }
+}
+template <class PP>
+__device__ __forceinline__ void observe6(PP p, const float* y, const float* path, const float* sp, float* o) {
+    const float e_ang[3] = {angle_error(sp[3], y[3]), angle_error(sp[4], y[4]), angle_error(sp[5], y[5])};
+    observe6e(p, y, path, e_ang, o);
 }
 
 // Random episode initialisation.  The reference's own random branch is broken for 6-DoF (6DoF.py:497 raises);
@@ -542,10 +561,15 @@ __device__ __forceinline__ void random_init6(uint64_t seed, int64_t gid, uint32_
     Philox4 r0 = philox4x32_10(g0, g1, epoch, 0u, k0, k1);
     Philox4 r1 = philox4x32_10(g0, g1, epoch, 1u, k0, k1);
     Philox4 r2 = philox4x32_10(g0, g1, epoch, 2u, k0, k1);
+    // u01's scale 2^-24, pinned HERE: left to itself LLVM hoists the literal out of the step loop of the fused launch into a VGPR
+    // that then lives (or is spilled) across the whole RK4 loop for the sake of the few lanes that reset
+    const float s24 = in_vgpr(1.0f / 16777216.0f);
+#define u01(x) ((float)((x) >> 8) * s24)
     path[0] = (u01(r0.v[0]) - 0.5f) * 10.f; path[1] = (u01(r0.v[1]) - 0.5f) * 10.f; path[2] = (u01(r0.v[2]) - 0.5f) * 10.f;
     path[3] = (u01(r0.v[3]) - 0.5f) * 10.f; path[4] = (u01(r1.v[0]) - 0.5f) * 10.f; path[5] = (u01(r1.v[1]) - 0.5f) * 10.f;
     ang[0] = u01(r1.v[2]) * MVRL_TWO_PI_HI; ang[1] = u01(r1.v[3]) * MVRL_TWO_PI_HI; ang[2] = u01(r2.v[0]) * MVRL_TWO_PI_HI;
     toffset = u01(r2.v[1]) * t_quarter;
+#undef u01
 }
 
 // SoA planes.  TOLD/TIME (the PID's tOld and the env's accumulated time, 6DoF.py:40,534) are only touched by the
@@ -644,6 +668,9 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     Pid6 pid;
     int istep = 0;
     float toff = 0.f;
+#if MVRL_BAM
+    uint32_t bam[3] = {0u, 0u, 0u};   // phi, theta, psi of the pose as binary angles; across the RK4 loop they wait in LDS
+#endif
 #pragma nounroll
     for (int kstep = 0; kstep < k_steps; kstep++) {
     const float* const actions_k = (MULTI && io.actions) ? io.actions + (size_t)kstep * (size_t)io.n * 6 : io.actions;
@@ -677,6 +704,12 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
 #pragma unroll
         for (int k = 0; k < 6; k++) { pid.eold[k] = ST(R6_EOLD + k); pid.eint[k] = ST(R6_EINT + k); }
     }
+#if MVRL_BAM
+    // the angle planes hold binary angles (mvrl_device.hpp); here y[3..5] carry their bit patterns (also from one step of a fused
+    // launch to the next)
+#pragma unroll
+    for (int k = 0; k < 3; k++) bam[k] = (uint32_t)unpack_int(y[3 + k]);
+#endif
     // set-point inputs, branch-free (one basic block up to the RK4 loop lets the gathers leave before anything waits
     // on the bulk of the state): fixed set-point -> the stored planes (6DoF.py:536-541), else the action row
     float spin[6];
@@ -700,24 +733,60 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     // the start of the step, z = pose_start - pose (it starts at 0), and the controller adds E0 = setPoint - pose_start, which
     // waits in LDS (pid6).  Either way pose = origin - z with origin = setPoint (action mode) or pose_start (fixed mode).
     constexpr bool fixed = FIXED;
+#if MVRL_BAM
+    const float c_rad = in_vgpr(MVRL_BAM_RAD);   // radians per binary-angle unit, pinned here (see bam_to_rad)
+#endif
     float z0[6], org[6];
+#if MVRL_BAM
+    float e_ang[3] = {0.f, 0.f, 0.f};   // angleError(setPoint, angles) at the end of the step, for the observation
+#endif
 #pragma unroll
     for (int k = 0; k < 6; k++) {  // 6DoF.py:545-552
         const float da = spin[k] * p->act_scale[k];
-        sp[k] = fixed ? spin[k] : da + y[k];
-        z0[k] = fixed ? spin[k] - y[k] : da;          // the error at the start of the step (yaw: unwrapped)
-        org[k] = fixed ? y[k] : sp[k];
+#if MVRL_BAM
+        // an angle as an ordinary fp32 number (signed, two roundings): good enough for what still uses absolute angles - the origin of
+        // lanes that take a full sincos inside the loop, re-anchoring at n_sub > 4; the step's own sincos and pose update use the bits
+        const float yk = (k >= 3) ? bam_to_rad(bam[k >= 3 ? k - 3 : 0], c_rad) : y[k];
+#else
+        const float yk = y[k];
+#endif
+        sp[k] = fixed ? spin[k] : da + yk;
+        z0[k] = fixed ? spin[k] - yk : da;          // the error at the start of the step (yaw: unwrapped)
+        org[k] = fixed ? yk : sp[k];
     }
+#if MVRL_BAM
+    if (fixed) {
+        // the reference's roll and pitch errors are plain differences setPoint - angle with the angle in [0, 2 pi) (6DoF.py:56-58);
+        // formed here from the binary angle's hi + lo pair (the yaw error is wrapped by the controller: any branch will do)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float hi, lo;
+            bam_to_rad2(bam[k], hi, lo);
+            const bool neg = (k < 2) && (hi < 0.f);
+            z0[3 + k] = (((spin[3 + k] - (neg ? MVRL_TWO_PI_HI : 0.f)) - hi) - lo) - (neg ? MVRL_TWO_PI_LO : 0.f);
+        }
+    }
+#endif
     if (first) {
 #pragma unroll
         for (int k = 0; k < 5; k++) pid.eold[k] = z0[k];
         pid.eold[5] = angle_error(z0[5], 0.f);
     }
+#if MVRL_BAM
+    if (fixed) {
+        e0s.put(z0, __uint_as_float(bam[2]));
+#pragma unroll
+        for (int k = 0; k < 6; k++) z0[k] = 0.f;
+    } else {
+        e0s.put_spare(__uint_as_float(bam[2]));
+    }
+#else
     if (fixed) {
         e0s.put(z0);
 #pragma unroll
         for (int k = 0; k < 6; k++) z0[k] = 0.f;
     }
+#endif
 
     const float h_s = io.dt / (float)io.n_sub;
     const float h = in_vgpr(h_s), hh = in_vgpr(0.5f * h_s), h6 = in_vgpr(h_s / 6.f);
@@ -759,8 +828,16 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     } else
 #endif
     {
+#if MVRL_BAM
+    sps.put(org, __uint_as_float(bam[0]), __uint_as_float(bam[1]));
+    Trig6 tb;              // attitude at the start of the step: the one full sincos of the step, of the binary angles
+    sincos_bam(bam[0], tb.sph, tb.cph, c_rad);
+    sincos_bam(bam[1], tb.sth, tb.cth, c_rad);
+    sincos_bam(bam[2], tb.sps, tb.cps, c_rad);
+#else
     sps.put(org);
     Trig6 tb = trig6(y);   // attitude at the start of the step: the one full sincos of the step (FAITHFUL: base of the first sub-step)
+#endif
 #pragma unroll
     for (int q = 0; q < 6; q++) y[q] = z0[q];          // from here to the end of the loop y[0..5] is the ERROR setPoint - pose
     for (int ks = 0; ks < io.n_sub; ks++) {
@@ -929,19 +1006,52 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
         }
     }
     sps.get(org);
+#if MVRL_BAM
+    // The attitude leaves the loop as the error z_end = origin - angle; the step moved the angle by z_start - z_end, a small number
+    // that is ADDED to the step's binary start angle (one rounding of ~1e-8 rad; the wrap of 6DoF.py:560 is the integer overflow).
+    // What the observation needs of the angles is their error against the set-point: z_end itself in the action mode (set-point =
+    // origin), E0 + z_end with a fixed set-point.
+    {
+        float b0, b1, b2, bx;
+        sps.get_extra(b0, b1);
+        e0s.get_extra(b2, bx);
+        bam[0] = __float_as_uint(b0); bam[1] = __float_as_uint(b1); bam[2] = __float_as_uint(b2);
+        float e0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (fixed) e0s.get(e0);
+        const float c_rad_e = in_vgpr(MVRL_BAM_RAD), c_bam_e = in_vgpr(MVRL_RAD_BAM);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            // z at the start of the step: a * scale again, from the action row (three cached loads instead of three registers
+            // that would live across the whole RK4 loop)
+            const float zs = fixed ? 0.f : actions_k[(size_t)i_in * 6 + 3 + k] * p->act_scale[3 + k];
+            e_ang[k] = angle_error((fixed ? e0[3 + k] : 0.f) + y[3 + k], 0.f);
+            if (!fixed) sp[3 + k] = zs + bam_to_rad_pos(bam[k], c_rad_e);              // 6DoF.py:545-552 with the angle in [0, 2 pi)
+            bam[k] = bam_add(bam[k], zs - y[3 + k], c_bam_e);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) y[q] = org[q] - y[q];   // back to the position
+    if (!fixed) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) sp[q] = org[q];
+    }
+#else
 #pragma unroll
     for (int q = 0; q < 6; q++) y[q] = org[q] - y[q];   // back to the pose
     if (!fixed) {
 #pragma unroll
         for (int q = 0; q < 6; q++) sp[q] = org[q];
     }
+#endif
     }
 #ifdef MVRL_STAMP_ON
     asm volatile("" : "+v"(y[0]), "+v"(y[11]));
     STAMP(2);
 #endif
-    // 6DoF.py:560
+#if !MVRL_BAM
+    // 6DoF.py:560 (binary angles wrap by themselves)
     y[3] = mod_two_pi(y[3]); y[4] = mod_two_pi(y[4]); y[5] = mod_two_pi(y[5]);
+#endif
     // The epilogue addresses the same SoA planes as the prologue.  Left alone, LLVM keeps all ~40 prologue
     // addresses alive in VGPR pairs across the whole RK4 loop (~75 registers, the difference between 2 and 3 waves
     // per SIMD) instead of recomputing them; hiding the lane index behind an empty asm makes it recompute.
@@ -957,7 +1067,11 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
         for (int k = 0; k < 6; k++) sp[k] = ST(R6_SP + k);
     }
     float o[9];
+#if MVRL_BAM
+    observe6e(p, y, path, e_ang, o);
+#else
     observe6(p, y, path, sp, o);
+#endif
     const bool done = istep >= io.max_steps;  // 6DoF.py:569-571
 
     reward_k[i] = 0.f;  // 6DoF.py:575
@@ -988,6 +1102,9 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
 #pragma unroll
         for (int q = 0; q < 6; q++) { pid.eold[q] = 0.f; pid.eint[q] = 0.f; }
         istep = 0;
+#if MVRL_BAM
+        bam[0] = 0u; bam[1] = 0u; bam[2] = 0u;
+#endif
         observe6(p, y, path, sp, o);
     }
 #if (MVRL_STORE_SC1 & 2)
@@ -996,6 +1113,10 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
 #else
 #pragma unroll
     for (int q = 0; q < 9; q++) obs_k[(size_t)i * 9 + q] = o[q];
+#endif
+#if MVRL_BAM
+#pragma unroll
+    for (int k = 0; k < 3; k++) y[3 + k] = pack_int((int)bam[k]);   // the angle words are bit patterns again
 #endif
     if (!MULTI || kstep == k_steps - 1) {
         // STW: the state planes' final stores (coalesced 256-B rows per wave); MVRL_STORE_SC1 bit 0 makes them write-through
@@ -1094,6 +1215,10 @@ __global__ __launch_bounds__(MVRL_BLOCK) void rov6_observe_kernel(const Rov6Dev*
     float y[12], path[6], sp[6], o[9];
 #pragma unroll
     for (int q = 0; q < 12; q++) y[q] = st[(R6_Y + q) * n];
+#if MVRL_BAM
+#pragma unroll
+    for (int q = 3; q < 6; q++) y[q] = bam_to_rad_pos((uint32_t)unpack_int(y[q]));
+#endif
 #pragma unroll
     for (int q = 0; q < 6; q++) { path[q] = st[(R6_PATH + q) * n]; sp[q] = st[(R6_SP + q) * n]; }
     observe6(p, y, path, sp, o);

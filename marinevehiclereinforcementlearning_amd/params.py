@@ -14,7 +14,7 @@ import numpy as np
 
 MODEL_AUV, MODEL_ROV3, MODEL_ROV6 = 0, 1, 2
 CTRL_FAITHFUL, CTRL_ZOH = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MODEL_NAMES = {"auv": MODEL_AUV, "rov3": MODEL_ROV3, "rov6": MODEL_ROV6}
 #            act, obs, init, state_words, aux
@@ -29,6 +29,8 @@ STATE_PLANES = {
     MODEL_AUV: dict(pose=slice(0, 6), heading_target=6, herr_o=7, perr_o=slice(8, 10), mult=slice(10, 21), toffset=21,
                     hist=slice(22, 52), istep=52, iwp=53, episode=54, phase=55),
 }
+# planes that hold BINARY ANGLES in an fp32 handle's state (bit pattern b of a uint32: angle = b * 2 pi / 2^32; include/mvrl.h)
+ANGLE_PLANES = {MODEL_ROV6: (3, 4, 5), MODEL_ROV3: (2,), MODEL_AUV: ()}
 PREC_F32, PREC_F64 = 0, 1
 INTEG_RK4, INTEG_RK45 = 0, 1
 

@@ -149,3 +149,72 @@ def test_turbulence_lookup_at_and_beyond_the_table_edges(oracle_mod):
                 assert max_scaled_err(h.get_state()[:6].T, pose_ref) < tol, (precision, entry, k)
                 assert max_scaled_err(o, o_ref) < max(tol, 1e-9) and max_scaled_err(r, r_ref) < max(tol * 3, 1e-9), (precision, entry, k)
             h.close()
+
+
+# ---- binary angles (ABI 3): the Euler-angle planes of the fp32 rigid-body handles -------------------------------------------------
+@pytest.mark.parametrize("dof", [6, 3])
+def test_binary_angle_planes_round_trip_and_wrap(oracle_mod, dof):
+    """The angle words of an fp32 handle are uint32 binary angles (include/mvrl.h): 0 after reset; Handle.get_state decodes them to
+    fp32 radians in [0, 2 pi) and set_state encodes (2.4e-7 rad, the resolution of the fp32 number handed in); unchanged entries are
+    restored bit for bit; and a vehicle turning THROUGH 0 / 2 pi - the wrap of 6DoF.py:560 / 3DoF.py:480, here an integer overflow - stays
+    on the fp64 oracle's trajectory on the circle, set-point and observation included."""
+    npos = 3 if dof == 6 else 2
+    planes = list(P.ANGLE_PLANES[P.MODEL_ROV6 if dof == 6 else P.MODEL_ROV3])
+    n = 256
+    model = "rov6" if dof == 6 else "rov3"
+    h = _lib.Handle(P.make_config(model, n, auto_reset=False, max_steps=10 ** 9, use_flow=False))
+    rng = np.random.default_rng(4)
+    init = np.concatenate([(rng.random((n, 2 * npos)) - 0.5) * 2.0, rng.random((n, dof - npos)) * 2 * np.pi], axis=1).astype(np.float32)
+    h.reset(init=init)
+    raw = h.get_state(raw=True)
+    assert not raw[planes].view(np.uint32).any()                                   # pose angles 0 after reset: bit pattern 0
+    # encode / decode: headings just below 2 pi, just above 0, and everywhere else
+    ang = (rng.random((len(planes), n)) * 2 * np.pi).astype(np.float32)
+    ang[:, :8] = np.float32(2 * np.pi) - np.float32([1e-6, 5e-7, 1e-4, 1e-3, 1e-2, 0.1, 0.2, 0.3])
+    ang[:, 8:12] = np.float32([0.0, 1e-7, 1e-4, 1e-2])
+    st = h.get_state()
+    st[planes] = ang
+    h.set_state(st)
+    back = h.get_state()
+    d = np.abs(back[planes].astype(np.float64) - ang)
+    d = np.minimum(d, 2 * np.pi - d)
+    assert d.max() < 5e-7 and np.all(back[planes] >= 0) and np.all(back[planes] < np.float32(2 * np.pi))
+    bits = h.get_state(raw=True)[planes].view(np.uint32).copy()
+    assert np.allclose(bits.astype(np.float64) * (2 * np.pi / 2 ** 32), np.mod(ang.astype(np.float64), 2 * np.pi), atol=8e-10, rtol=0)
+    h.set_state(back)                                                              # unchanged entries: the same bits go back
+    assert np.array_equal(h.get_state(raw=True)[planes].view(np.uint32), bits)
+    st2 = back.copy()
+    st2[-2] += 0.25                                                                # edit ANOTHER plane (flow time offset): angles keep their bits
+    h.set_state(st2)
+    assert np.array_equal(h.get_state(raw=True)[planes].view(np.uint32), bits)
+    # through the wrap: every env starts 0.02 rad either side of 0 / 2 pi in every angle and is steered across it
+    start = np.where(rng.random((n, dof - npos)) < 0.5, 2 * np.pi - 0.02, 0.02) + (rng.random((n, dof - npos)) - 0.5) * 0.01
+    st = h.get_state()
+    st[planes] = start.T.astype(np.float32)
+    h.set_state(st)
+    st = h.get_state()                                                             # what the handle holds now (decoded), as the oracle's start
+    env = oracle_mod.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9)
+    env.reset(init.astype(np.float64))
+    env.y[:, npos:dof] = st[planes].T.astype(np.float64)
+    # exact start angles for the oracle: the bits, not their fp32 decoding
+    env.y[:, npos:dof] = (h.get_state(raw=True)[planes].view(np.uint32).astype(np.float64) * (2 * np.pi / 2 ** 32)).T
+    crossed = np.zeros(n, bool)
+    for k in range(12):
+        a = rng.uniform(-1, 1, (n, dof)).astype(np.float32)
+        a[:, npos:] = np.where(start > np.pi, 1.0, -1.0) * np.abs(a[:, npos:])       # towards and across the wrap
+        o_ref, _, _ = env.step(a.astype(np.float64))
+        o_gpu, _, _ = h.step(a)
+        got = h.get_state()
+        y = got[: 2 * dof].T.astype(np.float64)
+        d = np.abs(y - env.y)
+        d[:, npos:dof] = np.minimum(d[:, npos:dof], 2 * np.pi - d[:, npos:dof])
+        err = (d / np.maximum(1.0, np.abs(env.y))).max(axis=1)
+        crossed |= (np.abs(env.y[:, npos:dof] - start) > np.pi).any(axis=1)
+        ok = err < 1e-5
+        assert ok.mean() > 0.98, (k, float(np.sort(err)[-5:].min()))
+        assert np.all(got[planes] >= 0) and np.all(got[planes] < np.float32(2 * np.pi))
+        assert np.max(np.abs(o_gpu[ok] - o_ref[ok])) < 2e-5
+        sp_gpu = got[4 * dof:5 * dof].T.astype(np.float64)                         # set-point planes: a * scale + angle in [0, 2 pi)
+        assert max_scaled_err(sp_gpu[ok], env.sp[ok]) < 1e-5
+    assert crossed.mean() > 0.5                                                    # the wrap really was exercised
+    h.close()

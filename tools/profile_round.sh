@@ -9,7 +9,7 @@
 # `--specialize` arguments are fine under the profiler: the hipcc child of mvrl_specialize gets a scrubbed environment (no
 # LD_PRELOAD / ROCP_* / HSA_TOOLS_*: mvrl_abi.hip child_environment), so the tool library does not follow into the compiler.
 WL=${1:-c4}
-TAG=${2:-r03_$WL}
+TAG=${2:-r04_$WL}
 shift 2
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out

@@ -2,7 +2,7 @@
 """Condense the raw rocprofv3 output of tools/profile_round.sh (gpurun_out/prof_<tag>_{kt,pmc*}) into the tracked summaries:
 
    profiles/<tag>_kernel_stats.csv   the --kernel-trace --stats table of the bench command (top rows)
-   profiles/r03_counters.json        per workload: HBM bytes per env step (FETCH_SIZE / WRITE_SIZE), VALU instruction counts,
+   profiles/<round>_counters.json    (round = the tag's prefix, r04_c4 -> r04) per workload: HBM bytes per env step (FETCH_SIZE / WRITE_SIZE), VALU instruction counts,
                                      wave cycles, effective clock - keyed by the kernel-source hash bench.py checks
 
     python tools/summarize_counters.py <tag> <workload> <kernel substring> <n_envs> <algorithmic read B> <algorithmic B>
@@ -102,7 +102,7 @@ def main():
             v["effective_clock_GHz_under_profiler"] = c["GRBM_GUI_ACTIVE"] / 8.0 / dur_ns
             v["kernel_us_under_profiler"] = dur_ns / 1e3
         ent["valu"] = v
-    path = os.path.join(PROF, "r03_counters.json")
+    path = os.path.join(PROF, f"{tag.split('_')[0]}_counters.json")
     data = json.load(open(path)) if os.path.exists(path) else {"workloads": {}}
     # identity of the build that was PROFILED: the bench line printed under the profiler carries it
     khash = None
