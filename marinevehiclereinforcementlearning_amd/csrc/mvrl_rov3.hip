@@ -348,7 +348,12 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[6], acc[6], yt[6];
         float* const aux_last = (ks == io.n_sub - 1) ? aux_row : nullptr;
+#if MVRL_BAM
+        // ZOH: every sub-step; FAITHFUL: re-anchored every fourth - at the binary start heading + what the step has turned so far
+        if (ks > 0 && (ZOH || (ks & 3) == 0)) sincos_bam(bam_add(bpsi, z0[2] - y[2]), tb.s, tb.c);
+#else
         if (ks > 0 && (ZOH || (ks & 3) == 0)) tb = trig1(org[2] - y[2]);   // ZOH: every sub-step; FAITHFUL: re-anchored every fourth
+#endif
         if (ZOH) {
             float F[4];
             if (first && ks == 0) control3<false, false>(p, y, pid, 0.f, 1e9f, nullptr, false, tb.c, tb.s, F, aux_last, fixed, e0);

@@ -506,6 +506,28 @@ __device__ __forceinline__ Trig6 stage3_trig(const Trig6& t2, const Trig6& tb, c
 #endif
 }
 
+#if MVRL_BAM
+// Full sincos of the attitude in the MIDDLE of a step (ZOH: every sub-step after the first; FAITHFUL: the re-anchoring of the base
+// attitude every fourth sub-step when n_sub > 4) from the binary angles: start angle (waiting in LDS) + what the step has turned so
+// far = z at the start of the step (a * scale, from the action row again; 0 with a fixed set-point) - z now.
+template <class PP>
+__device__ __forceinline__ Trig6 trig6_now(PP p, const SpStore& sps, const SpStore& e0s, const float* arow, bool fixed, const float* z) {
+    float b0, b1, b2, bx;
+    sps.get_extra(b0, b1);
+    e0s.get_extra(b2, bx);
+    const uint32_t b[3] = {__float_as_uint(b0), __float_as_uint(b1), __float_as_uint(b2)};
+    float s[3], c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float zs = fixed ? 0.f : arow[3 + k] * p->act_scale[3 + k];
+        sincos_bam(bam_add(b[k], zs - z[3 + k]), s[k], c[k]);
+    }
+    Trig6 t;
+    t.sph = s[0]; t.cph = c[0]; t.sth = s[1]; t.cth = c[1]; t.sps = s[2]; t.cps = c[2];
+    return t;
+}
+#endif
+
 // One RHS evaluation in FAITHFUL mode = BlueROV2Heavy6DoF.derivs (6DoF.py:406-442), PID state mutated.
 // timeHistory columns F0..F5 (controller output) and u0..u7 (rpm) of the LAST derivs call of a step (6DoF.py:578-587)
 template <class PP>
@@ -847,7 +869,11 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
         if (ZOH) {
             // PID + allocation once per sub-step; t - tOld = h except for the very first call after reset (= 0)
             Trig6 t = tb;
+#if MVRL_BAM
+            if (ks > 0) t = trig6_now(p, sps, e0s, FIXED ? nullptr : actions_k + (size_t)i_in * 6, fixed, y);
+#else
             if (ks > 0) t = trig6_err(sps, y);
+#endif
             Axes ax = body_axes(t);
             float u[6], F[8];
             const bool very_first = first && (ks == 0);
@@ -922,7 +948,11 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             for (int q = 0; q < 6; q++) dp[q] = inc_prev[q];
             // the sub-step's base attitude: the three later stages rotate it (stage_trig), and so does the next sub-step
             // (re-anchored by a full evaluation at the first sub-step of an env step and every fourth one after it)
+#if MVRL_BAM
+            if (ks > 0 && (ks & 3) == 0) tb = trig6_now(p, sps, e0s, FIXED ? nullptr : actions_k + (size_t)i_in * 6, fixed, y);   // re-anchored every fourth sub-step (n_sub > 4 only)
+#else
             if (ks > 0 && (ks & 3) == 0) tb = trig6_err(sps, y);   // re-anchored every fourth sub-step (n_sub > 4 only)
+#endif
 #ifdef MVRL_PARK_ON
             {
                 // same arithmetic, same order of operations as below; y and acc live in LDS between the stages

@@ -45,7 +45,7 @@ def main():
     kw = dict(n_substeps=n_sub, control_mode=mode)
     # calibration of the perturbation ensemble: its median deviation on ordinary envs, for three noise levels
     calm_lanes = np.nonzero(~audit.bad)[0][:256]
-    for nz in (1e-8, 2e-8, 3e-8, 5e-8, 1e-7):
+    for nz in (5e-9, 1e-8, 1.5e-8, 2e-8, 3e-8, 5e-8, 1e-7):
         _, med = ensemble_sensitive(oracle_mod, dof, init, actions, calm_lanes, np.full(len(calm_lanes), steps - 1), kw, members=8, noise=nz,
                                     return_median=True)
         print(f"  ensemble noise {nz:.0e}: median deviation of perturbed fp64 runs on 256 ordinary envs {med:.2e} (GPU median {q[0]:.2e})")

@@ -112,7 +112,7 @@ def test_random_batch_vs_fp64_oracle(oracle_mod, dof, mode, n_sub):
     o_gpu = h.reset(init=init)
     assert max_scaled_err(o_gpu, o_ref) < TOL
     ang = [3, 4, 5] if dof == 6 else [2]
-    audit = OutlierAudit(n, TOL, dof=dof, smooth_tol=SMOOTH_TOL_NSUB8 if n_sub == 8 else None)
+    audit = OutlierAudit(n, TOL, dof=dof)      # (rounds 2-3 needed a wider jump line at n_sub 8: the accepted drift reached 6-8e-5 there; with binary angles it is 10 x smaller)
     med = 0.0
     for s in range(steps):
         o_ref, _, _ = env.step(actions[s].astype(np.float64))
