@@ -509,17 +509,17 @@ __device__ __forceinline__ Trig6 stage3_trig(const Trig6& t2, const Trig6& tb, c
 #if MVRL_BAM
 // Full sincos of the attitude in the MIDDLE of a step (ZOH: every sub-step after the first; FAITHFUL: the re-anchoring of the base
 // attitude every fourth sub-step when n_sub > 4) from the binary angles: start angle (waiting in LDS) + what the step has turned so
-// far = z at the start of the step (a * scale, from the action row again; 0 with a fixed set-point) - z now.
-template <class PP>
-__device__ __forceinline__ Trig6 trig6_now(PP p, const SpStore& sps, const SpStore& e0s, const float* arow, bool fixed, const float* z) {
-    float b0, b1, b2, bx;
+// far = z at the start of the step (a * scale, waiting in LDS next to it; 0 with a fixed set-point) - z now.
+__device__ __forceinline__ Trig6 trig6_now(const SpStore& sps, const SpStore& e0s, bool fixed, const float* z) {
+    float b0, b1, b2, bx, e0[6];
     sps.get_extra(b0, b1);
     e0s.get_extra(b2, bx);
+    e0s.get(e0);
     const uint32_t b[3] = {__float_as_uint(b0), __float_as_uint(b1), __float_as_uint(b2)};
     float s[3], c[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const float zs = fixed ? 0.f : arow[3 + k] * p->act_scale[3 + k];
+        const float zs = fixed ? 0.f : e0[3 + k];
         sincos_bam(bam_add(b[k], zs - z[3 + k]), s[k], c[k]);
     }
     Trig6 t;
@@ -795,12 +795,12 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
         pid.eold[5] = angle_error(z0[5], 0.f);
     }
 #if MVRL_BAM
+    // the start-of-step error waits in LDS in BOTH modes: E0 for the controller (fixed), a * scale for the pose update at the end of
+    // the step (action mode: angle' = binary start angle + (z_start - z_end)); the third binary angle rides in its spare word
+    e0s.put(z0, __uint_as_float(bam[2]));
     if (fixed) {
-        e0s.put(z0, __uint_as_float(bam[2]));
 #pragma unroll
         for (int k = 0; k < 6; k++) z0[k] = 0.f;
-    } else {
-        e0s.put_spare(__uint_as_float(bam[2]));
     }
 #else
     if (fixed) {
@@ -870,7 +870,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             // PID + allocation once per sub-step; t - tOld = h except for the very first call after reset (= 0)
             Trig6 t = tb;
 #if MVRL_BAM
-            if (ks > 0) t = trig6_now(p, sps, e0s, FIXED ? nullptr : actions_k + (size_t)i_in * 6, fixed, y);
+            if (ks > 0) t = trig6_now(sps, e0s, fixed, y);
 #else
             if (ks > 0) t = trig6_err(sps, y);
 #endif
@@ -949,7 +949,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             // the sub-step's base attitude: the three later stages rotate it (stage_trig), and so does the next sub-step
             // (re-anchored by a full evaluation at the first sub-step of an env step and every fourth one after it)
 #if MVRL_BAM
-            if (ks > 0 && (ks & 3) == 0) tb = trig6_now(p, sps, e0s, FIXED ? nullptr : actions_k + (size_t)i_in * 6, fixed, y);   // re-anchored every fourth sub-step (n_sub > 4 only)
+            if (ks > 0 && (ks & 3) == 0) tb = trig6_now(sps, e0s, fixed, y);   // re-anchored every fourth sub-step (n_sub > 4 only)
 #else
             if (ks > 0 && (ks & 3) == 0) tb = trig6_err(sps, y);   // re-anchored every fourth sub-step (n_sub > 4 only)
 #endif
@@ -1046,14 +1046,12 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
         sps.get_extra(b0, b1);
         e0s.get_extra(b2, bx);
         bam[0] = __float_as_uint(b0); bam[1] = __float_as_uint(b1); bam[2] = __float_as_uint(b2);
-        float e0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (fixed) e0s.get(e0);
+        float e0[6];
+        e0s.get(e0);               // fixed: E0 = setPoint - pose at the start of the step; action mode: z at the start = a * scale
         const float c_rad_e = in_vgpr(MVRL_BAM_RAD), c_bam_e = in_vgpr(MVRL_RAD_BAM);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            // z at the start of the step: a * scale again, from the action row (three cached loads instead of three registers
-            // that would live across the whole RK4 loop)
-            const float zs = fixed ? 0.f : actions_k[(size_t)i_in * 6 + 3 + k] * p->act_scale[3 + k];
+            const float zs = fixed ? 0.f : e0[3 + k];
             e_ang[k] = angle_error((fixed ? e0[3 + k] : 0.f) + y[3 + k], 0.f);
             if (!fixed) sp[3 + k] = zs + bam_to_rad_pos(bam[k], c_rad_e);              // 6DoF.py:545-552 with the angle in [0, 2 pi)
             bam[k] = bam_add(bam[k], zs - y[3 + k], c_bam_e);
