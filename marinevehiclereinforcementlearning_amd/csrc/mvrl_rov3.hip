@@ -289,6 +289,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     // the heading plane holds a binary angle (mvrl_device.hpp "binary angles"; y[2] carries its bit pattern, also from one step of a
     // fused launch to the next): an ordinary fp32 copy for the origin of the rare full-sincos lanes, the bits for everything else
     const uint32_t bpsi = (uint32_t)unpack_int(y[2]);
+    float ys[2];
 #endif
 #pragma unroll
     for (int k = 0; k < 3; k++) {  // 3DoF.py:469-472
@@ -302,6 +303,9 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
         e0[k] = fixed ? spin[k] - yk : da;             // the error at the start of the step (yaw: unwrapped)
         org[k] = fixed ? yk : sp[k];                   // pose = org - z
         z0[k] = fixed ? 0.f : e0[k];
+#if MVRL_BAM
+        if (k < 2) ys[k] = yk;                         // start position: the step's displacement z_start - z_end is added to it at the end
+#endif
     }
 #if MVRL_BAM
     if (fixed) {   // the yaw error against a fixed set-point from the binary angle's hi + lo pair (wrapped by the controller)
@@ -409,7 +413,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     if (!fixed) sp[2] = z0[2] + bam_to_rad_pos(bpsi);                  // 3DoF.py:469-472 with the heading in [0, 2 pi)
     bpsi_new = bam_add(bpsi, z0[2] - y[2]);
 #pragma unroll
-    for (int q = 0; q < 2; q++) y[q] = org[q] - y[q];   // back to the position
+    for (int q = 0; q < 2; q++) y[q] = ys[q] + (z0[q] - y[q]);   // back to the position: one rounding at the size of the position
 #else
 #pragma unroll
     for (int q = 0; q < 3; q++) y[q] = org[q] - y[q];   // back to the pose

@@ -774,7 +774,14 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
 #endif
         sp[k] = fixed ? spin[k] : da + yk;
         z0[k] = fixed ? spin[k] - yk : da;          // the error at the start of the step (yaw: unwrapped)
+#if MVRL_BAM
+        // parked origin: for the angles the origin of the error coordinates (set-point or start angle: what a full sincos inside the
+        // loop needs); for the POSITION the start position itself - the step's displacement is added to it at the end (one rounding
+        // at the size of the position instead of two)
+        org[k] = (fixed || k < 3) ? yk : sp[k];
+#else
         org[k] = fixed ? yk : sp[k];
+#endif
     }
 #if MVRL_BAM
     if (fixed) {
@@ -1041,13 +1048,14 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     // that is ADDED to the step's binary start angle (one rounding of ~1e-8 rad; the wrap of 6DoF.py:560 is the integer overflow).
     // What the observation needs of the angles is their error against the set-point: z_end itself in the action mode (set-point =
     // origin), E0 + z_end with a fixed set-point.
+    float e0q[6];
+    e0s.get(e0q);                  // fixed: E0 = setPoint - pose at the start of the step; action mode: z at the start = a * scale
     {
         float b0, b1, b2, bx;
         sps.get_extra(b0, b1);
         e0s.get_extra(b2, bx);
         bam[0] = __float_as_uint(b0); bam[1] = __float_as_uint(b1); bam[2] = __float_as_uint(b2);
-        float e0[6];
-        e0s.get(e0);               // fixed: E0 = setPoint - pose at the start of the step; action mode: z at the start = a * scale
+        const float* e0 = e0q;
         const float c_rad_e = in_vgpr(MVRL_BAM_RAD), c_bam_e = in_vgpr(MVRL_RAD_BAM);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -1058,10 +1066,10 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
         }
     }
 #pragma unroll
-    for (int q = 0; q < 3; q++) y[q] = org[q] - y[q];   // back to the position
-    if (!fixed) {
-#pragma unroll
-        for (int q = 0; q < 3; q++) sp[q] = org[q];
+    for (int q = 0; q < 3; q++) {   // back to the position: start position + displacement, displacement = z_start - z_end
+        const float zs = fixed ? 0.f : e0q[q];
+        if (!fixed) sp[q] = zs + org[q];               // 6DoF.py:545-552
+        y[q] = org[q] + (zs - y[q]);
     }
 #else
 #pragma unroll

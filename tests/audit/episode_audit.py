@@ -76,9 +76,11 @@ def main():
         flo.step(a.astype(np.float64))
         for arr in (flo.y, flo.eold, flo.eint, flo.sp):
             arr[:] = arr.astype(np.float32)
-        efl = circ_err(flo.y, ref.y, ang).max(axis=1)
+        efc = circ_err(flo.y, ref.y, ang)
+        efl = efc.max(axis=1)
         a_flo.update(efl, ref.margins)
-        e = circ_err(h.get_state()[:2 * dof].T, ref.y, ang).max(axis=1)
+        ec = circ_err(h.get_state()[:2 * dof].T, ref.y, ang)
+        e = ec.max(axis=1)
         e32 = circ_err(low.y, ref.y, ang).max(axis=1)
         a_gpu.update(e, ref.margins)
         a_low.update(e32, ref.margins)
@@ -88,6 +90,12 @@ def main():
                   f"{np.median(e):.2e} {np.quantile(calm, 0.99):.2e} | {100 * a_low.bad.mean():7.3f} {int(a_low.smooth().sum()):7d} {int(a_low.jumped.sum()):7d} "
                   f"{int(a_low.unexplained().sum()):6d} {np.median(e32):.2e} | {100 * a_flo.bad.mean():7.3f} {np.median(efl):.2e}   [{time.time() - t0:.0f} s]", flush=True)
     assert np.isfinite(h.get_state()[:2 * dof]).all() and np.isfinite(ref.y).all()
+    names = ["x", "y", "z", "phi", "theta", "psi", "u", "v", "w", "p", "q", "r"] if dof == 6 else ["x", "y", "psi", "u", "v", "r"]
+    print("# last step, scaled error per state word, median / 90 % quantile over all envs - HIP kernel: " +
+          "  ".join(f"{nm} {np.median(ec[:, k]):.1e}/{np.quantile(ec[:, k], 0.9):.1e}" for k, nm in enumerate(names)))
+    print("#                                                                          storage floor: " +
+          "  ".join(f"{nm} {np.median(efc[:, k]):.1e}/{np.quantile(efc[:, k], 0.9):.1e}" for k, nm in enumerate(names)))
+    print("# median |state| at the last step: " + "  ".join(f"{nm} {np.median(np.abs(ref.y[:, k])):.2g}" for k, nm in enumerate(names)))
     # which discontinuity the explained jumps were next to
     ex = a_gpu.explained()
     kinds = np.argmin(a_gpu.margin_at_jump[ex] / a_gpu.bounds, axis=1) if ex.any() else np.zeros(0, int)
