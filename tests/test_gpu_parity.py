@@ -129,7 +129,7 @@ def test_random_batch_vs_fp64_oracle(oracle_mod, dof, mode, n_sub):
     # (tests/audit/err_quantiles.py, gpurun_out/r2_errq18.log) - bounded at twice the measured share
     audit.assert_explained(max_share=budget, max_smooth_share=0.001 if mode == P.CTRL_ZOH or n_sub == 8 else 0.0005,
                            resolver=make_resolver(oracle_mod, dof, init, actions, dict(n_substeps=n_sub, control_mode=mode)))
-    assert med < 2e-6, med
+    assert med < 6e-7, med      # round 3: 1.5-2.9e-6; with binary angles 1.7-2.7e-7 (gpurun_out/r4_bam_suite.log)
     h.close()
 
 
