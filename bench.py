@@ -374,6 +374,8 @@ def main():
     prewarm_s = time.perf_counter() - t_pre
     step_us_estimate = prewarm_s / max(1, pre_steps) * 1e6      # what a step takes on this device, for the chains' phase offset
     run_plain(W)
+    if stepper is not None:
+        stepper.phase_delay(step_us_estimate)   # first use of the delay kernel (lazy code-object load, ~100 ms) belongs to the warm-up
     sync()
     def timed_region(plan):
         """K steps between barrier + synchronize pairs under one launch plan; returns wall time (max over ranks), GPU time by
