@@ -439,9 +439,15 @@ def main():
             t_rep = torch.tensor([n_repeats], dtype=torch.int64, device=dev)
             dist.all_reduce(t_rep, op=dist.ReduceOp.MAX)
             n_repeats = int(t_rep.item())
-    for r in range(max(1, n_repeats)):
-        for pl in plans:
-            by_plan[pl].append(timed_region(pl))
+    import gc
+    gc.collect()
+    gc.disable()            # a collection inside a 2-ms region would be a 20-fold outlier (the median does not care, the list of repeats does)
+    try:
+        for r in range(max(1, n_repeats)):
+            for pl in plans:
+                by_plan[pl].append(timed_region(pl))
+    finally:
+        gc.enable()
 
     def repeat_list(vals):
         """all repeats when they are few; otherwise 33 evenly spaced order statistics (min ... median ... max) - `timing.repeats` says how many there were"""
