@@ -40,7 +40,8 @@ def main():
     print("  max-error quantiles of the envs that never jumped (50 / 90 / 99 / 99.9 / 99.99 %): " + " ".join(f"{x:.2e}" for x in q))
     print(f"  beyond 1e-5: {int(audit.bad.sum())} ({100 * audit.bad.mean():.3f} %), drifted (<= {SMOOTH_TOL:g}): {int(audit.smooth().sum())} "
           f"({100 * audit.smooth().mean():.4f} %), jumped: {int(audit.jumped.sum())}, unexplained: {int(audit.unexplained().sum())}")
-    from tests.parity_util import NAMES, ensemble_sensitive, ENSEMBLE_NOISE
+    from tests.parity_util import NAMES, ensemble_sensitive, ENSEMBLE_NOISE, ENSEMBLE_NOISE_3DOF
+    ENSEMBLE_NOISE = ENSEMBLE_NOISE if dof == 6 else ENSEMBLE_NOISE_3DOF
     un = np.nonzero(audit.unexplained())[0]
     kw = dict(n_substeps=n_sub, control_mode=mode)
     # calibration of the perturbation ensemble: its median deviation on ordinary envs, for three noise levels
