@@ -57,16 +57,19 @@ def main():
     ref = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft)
     low = orc.OracleRovEnv(dof, n, "f32", max_steps=10 ** 9, flow=ft)
     flo = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft)
+    fla = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft)      # ... the same floor with the ANGLES left exact (what binary angles buy)
     ref.reset(init, toffset=toff)
     low.reset(init, toffset=toff)
     flo.reset(init, toffset=toff)
+    fla.reset(init, toffset=toff)
     ang = [3, 4, 5] if dof == 6 else [2]
-    a_gpu, a_low, a_flo = OutlierAudit(n, 1e-5, dof=dof), OutlierAudit(n, 1e-5, dof=dof), OutlierAudit(n, 1e-5, dof=dof)
+    a_gpu, a_low, a_flo, a_fla = (OutlierAudit(n, 1e-5, dof=dof) for _ in range(4))
     rng = np.random.default_rng(2024)
     print(f"# whole-episode audit {which}: {h.variant}, {n} envs x {steps} steps, dt 0.2, n_sub 4, FAITHFUL, random resets + uniform actions, vs the fp64 oracle")
     print("# step | HIP fp32 kernel: beyond 1e-5 [%]  drifted  jumped(explained)  jumped(beyond the bounds)  median err  q99 of calm envs "
           "| fp32 build of the oracle: beyond 1e-5 [%]  drifted  jumped  beyond the bounds  median err "
-          "| fp64 oracle with fp32 state between steps (floor): beyond 1e-5 [%]  median err")
+          "| fp64 oracle with fp32 state between steps (floor): beyond 1e-5 [%]  median err "
+          "| the same floor with exact angles: beyond 1e-5 [%]  median err")
     t0 = time.time()
     for s in range(steps):
         a = rng.uniform(-1, 1, (n, dof)).astype(np.float32)
@@ -79,6 +82,13 @@ def main():
         efc = circ_err(flo.y, ref.y, ang)
         efl = efc.max(axis=1)
         a_flo.update(efl, ref.margins)
+        fla.step(a.astype(np.float64))
+        keep = fla.y[:, ang].copy()
+        for arr in (fla.y, fla.eold, fla.eint, fla.sp):
+            arr[:] = arr.astype(np.float32)
+        fla.y[:, ang] = keep
+        efa = circ_err(fla.y, ref.y, ang).max(axis=1)
+        a_fla.update(efa, ref.margins)
         ec = circ_err(h.get_state()[:2 * dof].T, ref.y, ang)
         e = ec.max(axis=1)
         e32 = circ_err(low.y, ref.y, ang).max(axis=1)
@@ -88,7 +98,7 @@ def main():
             calm = e[~a_gpu.jumped]
             print(f"{s + 1:4d} | {100 * a_gpu.bad.mean():7.3f} {int(a_gpu.smooth().sum()):7d} {int(a_gpu.explained().sum()):7d} {int(a_gpu.unexplained().sum()):6d} "
                   f"{np.median(e):.2e} {np.quantile(calm, 0.99):.2e} | {100 * a_low.bad.mean():7.3f} {int(a_low.smooth().sum()):7d} {int(a_low.jumped.sum()):7d} "
-                  f"{int(a_low.unexplained().sum()):6d} {np.median(e32):.2e} | {100 * a_flo.bad.mean():7.3f} {np.median(efl):.2e}   [{time.time() - t0:.0f} s]", flush=True)
+                  f"{int(a_low.unexplained().sum()):6d} {np.median(e32):.2e} | {100 * a_flo.bad.mean():7.3f} {np.median(efl):.2e} | {100 * a_fla.bad.mean():7.3f} {np.median(efa):.2e}   [{time.time() - t0:.0f} s]", flush=True)
     assert np.isfinite(h.get_state()[:2 * dof]).all() and np.isfinite(ref.y).all()
     names = ["x", "y", "z", "phi", "theta", "psi", "u", "v", "w", "p", "q", "r"] if dof == 6 else ["x", "y", "psi", "u", "v", "r"]
     print("# last step, scaled error per state word, median / 90 % quantile over all envs - HIP kernel: " +
