@@ -8,7 +8,7 @@ reformulations): the yardstick for what fp32 itself costs on this closed loop.  
 velocities, controller memory, set-point) is rounded to fp32 ONCE PER ENV STEP - what a kernel with exact arithmetic but the
 ABI's fp32 state planes would do; nothing that stores fp32 state between steps can be closer to the fp64 trajectory than that.
 
-    python tests/audit/episode_audit.py c4|c3|c2 [n] [steps]        (GPU box; writes to stdout)
+    python tests/audit/episode_audit.py c4|c3|c2|auv [n] [steps]        (GPU box; writes to stdout)
 """
 import os
 import sys
@@ -122,5 +122,67 @@ def main():
     h.close()
 
 
+def main_auv(n, steps):
+    """AuvEnv + turbulence (tag/verySimpleAuv.py): episodes end on the time limit (250 steps of 0.02 s) or when the vehicle leaves the
+    +-1 m box; an env counts while the fp64 oracle still runs it.  Reports the share of such envs whose pose left 1e-5, the envs that
+    terminated at a different step, and the same for the fp32 build of the oracle."""
+    flow = ReconstructedFlow.synthetic(n_modes=8, n_time=2000)
+    flow.scale(11., 1., 2., translate=(-1.65, -1.1))
+    uv = flow.table_uv()
+    auv = P.auv_params(noiseMagCoeffs=0.1, noiseMagActuation=0.1)
+    h = _lib.Handle(P.make_config("auv", n, dt=0.02, auto_reset=False, max_steps=steps, use_flow=True, seed=12345, auv=auv))
+    h.set_flow(uv, flow.dt, flow.dx, flow.dy)
+    h.reset()
+    st = h.get_state()
+    pl = P.STATE_PLANES[P.MODEL_AUV]
+    init = np.zeros((n, 16))
+    init[:, :3] = st[pl["pose"]][:3].T
+    init[:, 3] = st[pl["heading_target"]]
+    init[:, 4] = st[pl["toffset"]]
+    init[:, 5:] = st[pl["mult"]].T
+    ft = orc.FlowTable(uv.astype(np.float64), flow.dt, flow.dx, flow.dy)
+    ref = orc.OracleAuvEnv(n, "f64", dt=0.02, max_steps=steps, flow=ft, auv=auv)
+    low = orc.OracleAuvEnv(n, "f32", dt=0.02, max_steps=steps, flow=ft, auv=auv)
+    ref.reset(init)
+    low.reset(init)
+    rng = np.random.default_rng(2024)
+    alive = np.ones(n, bool)            # the oracle has not finished the env yet
+    bad, bad32 = np.zeros(n, bool), np.zeros(n, bool)
+    split, split32 = np.zeros(n, bool), np.zeros(n, bool)
+    worst_rew = 0.0
+    print(f"# whole-episode audit auv: {h.variant}, {n} envs x up to {steps} steps, dt 0.02, random resets + uniform actions, vs the fp64 oracle")
+    print("# step | envs still running | HIP fp32 kernel: % of them with the pose beyond 1e-5 (cumulative), terminated at another step, median pose err "
+          "| fp32 build of the oracle: % beyond, terminated at another step, median")
+    for s in range(steps):
+        a = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        o_ref, r_ref, d_ref = ref.step(a.astype(np.float64))
+        o32, r32, d32 = low.step(a)
+        o, r, d = h.step(a)
+        pose = h.get_state()[:6].T.astype(np.float64)
+
+        def perr(p_):
+            dd = np.abs(p_ - ref.pose)
+            dd[:, 2] = np.minimum(dd[:, 2], np.abs(dd[:, 2] - 2 * np.pi))
+            return (dd / np.maximum(1.0, np.abs(ref.pose))).max(axis=1)
+        e, e32 = perr(pose), perr(low.pose.astype(np.float64))
+        bad |= alive & (e > 1e-5)
+        bad32 |= alive & (e32 > 1e-5)
+        split |= alive & ((d != 0) != (d_ref != 0))
+        split32 |= alive & ((d32 != 0) != (d_ref != 0))
+        ok = alive & ~bad & ~split
+        if ok.any():
+            worst_rew = max(worst_rew, float((np.abs(r - r_ref) / np.maximum(1.0, np.abs(r_ref)))[ok].max()))
+        if (s + 1) in CHECKPOINTS or s + 1 == steps:
+            print(f"{s + 1:4d} | {int(alive.sum()):6d} | {100 * bad.mean():7.3f} {int(split.sum()):5d} {np.median(e[alive]) if alive.any() else 0:.2e} "
+                  f"| {100 * bad32.mean():7.3f} {int(split32.sum()):5d} {np.median(e32[alive]) if alive.any() else 0:.2e}", flush=True)
+        alive &= (d_ref == 0) & (d == 0)
+    print(f"# envs whose pose left 1e-5 while the oracle ran them: {int(bad.sum())} of {n} ({100 * bad.mean():.3f} %); terminated at another step: {int(split.sum())}; "
+          f"worst reward difference among the others {worst_rew:.1e}")
+    h.close()
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "auv":
+        main_auv(int(sys.argv[2]) if len(sys.argv) > 2 else 65536, int(sys.argv[3]) if len(sys.argv) > 3 else 250)
+    else:
+        main()
