@@ -16,7 +16,7 @@ VARIANTS = {
     # ablations of choices the default build makes
     "novs": dict(extra=["-DMVRL_NO_VGPR_SCALARS"], drop=()),          # RK step sizes left in SGPRs
     "auvscatter": dict(extra=["-DMVRL_AUV_LDS_OBS=0"], drop=()),      # AuvEnv observations stored row-per-lane
-    "blk256": dict(extra=["-DMVRL_STEP_BLOCK=256"], drop=()),
+    # ("blk256", -DMVRL_STEP_BLOCK=256, measured +2 % in round 2, no longer builds: the LDS parking tiles are sized for one-wave blocks)
     "blk32": dict(extra=["-DMVRL_STEP_BLOCK=32"], drop=()),           # half-filled waves: twice the waves for a launch-bound batch (C2)
     "slp": dict(extra=[], drop=("-fno-slp-vectorize",)),
     "nofast": dict(extra=[], drop=("-ffast-math",)),
