@@ -448,15 +448,18 @@ def test_rov6_with_turbulence_vs_oracle(oracle_mod, base_flow, where, pos_scale,
         h.close()
 
 
-FUZZ_SEEDS = [2024, 1, 2, 3, 4, 5, 6, 7, 8]
+# 25 seeds x 24 cases in the suite; seeds 25..64 were run once more by hand in round 4 (MVRL_FUZZ_SEEDS=..., gpurun_out/r4_fuzz_more.log): green
+FUZZ_SEEDS = [2024] + list(range(1, 25))
+if os.environ.get("MVRL_FUZZ_SEEDS"):      # exploratory: MVRL_FUZZ_SEEDS=9,10,11 python -m pytest tests/test_gpu_parity.py -m gpu -k config_fuzz
+    FUZZ_SEEDS = [int(x) for x in os.environ["MVRL_FUZZ_SEEDS"].split(",")]
 
 
 @pytest.mark.parametrize("seed", FUZZ_SEEDS)
 def test_config_fuzz_vs_oracle(oracle_mod, base_flow, seed):
     """Seeded sweep over combinations no other test pins: ragged batch sizes (1, 63, 65, 257, 1000: partial tail waves),
     odd sub-step counts, other dt, fixed set-point x turbulence x controller placement x kernel flavour.  Every case is
-    compared with the fp64 oracle for 8 env steps; tolerance 1e-5 with the usual outlier-lane accounting.  All nine seeds are
-    part of the suite (round 3 kept one and called the others exploratory)."""
+    compared with the fp64 oracle for 8 env steps; tolerance 1e-5 with the usual outlier-lane accounting.  All seeds are part of
+    the suite (round 3 kept one and called the others exploratory)."""
     from oracle import flow_ref
     base, bdx, bdy = base_flow[:3]
     fd, fdx, fdy, fdt = flow_ref.scale(base, bdx, bdy, BASE_DT, 11., 1., 2.)
@@ -494,10 +497,16 @@ def test_config_fuzz_vs_oracle(oracle_mod, base_flow, seed):
             low.step(actions[k])
             audit32.update(circ_err(low.y, env.y, ang).max(axis=1), env.margins)
             o_gpu, _, _ = h.step(None if fixed else actions[k])
-            e = circ_err(h.get_state()[: 2 * dof].T, env.y, ang).max(axis=1)
+            y_gpu = h.get_state()[: 2 * dof].T
+            e = circ_err(y_gpu, env.y, ang).max(axis=1)
             audit.update(e, env.margins)
             med = max(med, float(np.median(e)))
-            good = ~audit.bad
+            # observations are O(1) quantities with an ABSOLUTE bar, the state's bar is relative above 1: an angle of 3 rad may be 3e-5 rad
+            # off and within tolerance, which is 3.8e-5 in the observation (x 4 / pi).  The observation is therefore compared on envs whose
+            # angles agree to 1e-5 rad in absolute terms (exploratory seed 14: an env at cos(theta) = 0.06, state error 9.3e-6 relative)
+            d_ang = np.abs(y_gpu[:, ang].astype(np.float64) - env.y[:, ang])
+            d_ang = np.minimum(d_ang, np.abs(d_ang - 2 * np.pi)).max(axis=1)
+            good = ~audit.bad & (d_ang < TOL)
             if good.any():
                 assert max_scaled_err(o_gpu[good], o_ref[good]) < 2 * TOL, (case, k)
         bad = audit.bad
@@ -507,9 +516,17 @@ def test_config_fuzz_vs_oracle(oracle_mod, base_flow, seed):
               + f"\n   fp32 build of the oracle on the same case: {bad32} beyond tol, {drift32} drifted")
         # every env that jumped did so next to a discontinuity; envs that merely drifted past 1e-5 in 8 steps are bounded in number:
         # 1 % of the batch, or - where the case is ill-conditioned for fp32 as such - what the fp32 oracle build drifts (+25 % + 1)
+        un = np.nonzero(audit.unexplained())[0]
+        if len(un):
+            # a jump with no recorded discontinuity within the bounds (exploratory seed 36: one env of 1000 at 7.5e-5, cos(theta) 0.62, in the
+            # fixed-set-point x turbulence x ZOH corner where the fp32 oracle build loses 56 envs to the kernel's 17): accepted only where the
+            # fp32 build of the oracle has at least as many of the same kind on the same case - the case, not the kernel, is ill-conditioned
+            un32 = int(audit32.unexplained().sum())
+            assert len(un) <= un32, (report[-1], f"{len(un)} unexplained jumps, fp32 oracle build {un32}", audit.report())
+            audit.margin_at_jump[un] = 0.0
         audit.assert_explained(max_smooth_share=max(1.0 / n, FUZZ_MAX_DRIFT_SHARE, (1.25 * drift32 + 1) / n))
         assert bad.sum() <= max(1, int(FUZZ_MAX_BAD_SHARE * n), int(1.25 * bad32 + 1)), (report[-1], audit.report())
-        assert med < 3e-6, report[-1]
+        assert med < (3e-6 if n > 1 else TOL), report[-1]      # a batch of one env has no median: it must simply be within tolerance
         h.close()
     for r in report:
         print("fuzz case %2d dof %d n %4d n_sub %d dt %.1f mode %d fixed %d flow %d %-28s outliers %d median %.1e" % r)
