@@ -160,7 +160,6 @@ __device__ __forceinline__ uint32_t bam_add(uint32_t b, float d, float c_bam = M
     // ... where gfx950's v_cvt_i32_f32 saturates: a half turn comes out 1.5e-9 rad short at worst
     return b + (uint32_t)(int32_t)rintf(d * c_bam);
 }
-__device__ __forceinline__ uint32_t rad_to_bam(float a) { return bam_add(0u, a); }
 // sin and cos of a binary angle: the top two bits (after rounding to the nearest quadrant) ARE the Cody-Waite quotient, the remainder is
 // exact, and its conversion to radians carries its rounding error along (first-order correction): ~1 ulp of the RESULT for any angle
 __device__ __forceinline__ void sincos_bam(uint32_t b, float& s, float& c, float c_rad = MVRL_BAM_RAD) {

@@ -414,11 +414,6 @@ struct SpStore {
         const float4 b = const_cast<const float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]);
         x0 = b.z; x1 = b.w;
     }
-    __device__ __forceinline__ void put_spare(float x0) const {   // only the spare word (the six values are not in use)
-        float4 b; b.x = 0.f; b.y = 0.f; b.z = x0; b.w = 0.f;
-        const_cast<float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]) = b;
-        asm volatile("" ::: "memory");
-    }
     __device__ __forceinline__ void get(float* sp) const {
         asm volatile("" ::: "memory");
         const float4 a = const_cast<const float4&>(base[threadIdx.x]), b = const_cast<const float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]);
@@ -432,7 +427,6 @@ struct SpStore {   // no parking (fp64 build, MVRL_NO_PARK): the set-point stays
     __device__ __forceinline__ void put(const float* sp, float x0 = 0.f, float x1 = 0.f) { for (int q = 0; q < 6; q++) v[q] = sp[q]; x[0] = x0; x[1] = x1; }
     __device__ __forceinline__ void get(float* sp) const { for (int q = 0; q < 6; q++) sp[q] = v[q]; }
     __device__ __forceinline__ void get_extra(float& x0, float& x1) const { x0 = x[0]; x1 = x[1]; }
-    __device__ __forceinline__ void put_spare(float x0) { x[0] = x0; }
 };
 #endif
 
