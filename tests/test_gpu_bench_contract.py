@@ -59,22 +59,24 @@ def test_other_workload_and_plan():
     assert j["config"]["kernel"].startswith("auv/")
 
 
-def test_plain_command_launches_its_own_ranks():
-    """`python bench.py --gpus 2` - no torchrun, no wrapper script - starts its two ranks itself (bench.self_launch, before
+@pytest.mark.parametrize("world", [2, 4])
+def test_plain_command_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` (N = 2 and 4: four ranks are within the box's limit of six GPU processes) - no torchrun, no wrapper script - starts its ranks itself (bench.self_launch, before
     anything touches the GPU), prints ONE JSON line and returns 0.  On the one-GPU box the two ranks share the card over gloo
     (the rehearsal knobs; RCCL refuses duplicate devices) - everything else is the path the driver's N = 2/4/8 runs take:
     rendezvous, sharded step, gather pipeline, max-over-ranks timing."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(MVRL_BENCH_BACKEND="gloo", MVRL_BENCH_SAME_DEVICE="1")
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "8", "--repeats", "3",
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(world), "--steps", "16", "--warmup", "8", "--repeats", "3",
                         "--prewarm-s", "0.05", "--envs-per-gpu", "131072"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-500:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["config"]["global_envs"] == 2 * 131072
-    assert j["rccl"]["world_size_seen"] == 2
+    assert j["n_gpus"] == world and j["config"]["global_envs"] == world * 131072
+    assert j["rccl"]["world_size_seen"] == world and not j["rccl"]["ranks_on_distinct_devices"]      # the rehearsal shares one card
     assert j["with_gather"]["value"] is not None and j["with_gather"]["value"] > 0
     assert "cpu_baseline" not in j          # rank 0 at N = 1 only
-    assert abs(j["value"] - 2 * 131072 * 16 / (j["ms_per_step"] * 1e-3 * 16)) / j["value"] < 1e-9
+    assert abs(j["value"] - world * 131072 * 16 / (j["ms_per_step"] * 1e-3 * 16)) / j["value"] < 1e-9
+    assert j["with_gather"]["bytes_per_step_at_root"] == (131072 * 37 + 15) // 16 * 16 * world      # obs | done per rank, padded
 
