@@ -242,6 +242,12 @@ int mvrl_step_range_dev(mvrl_handle* h, int64_t first_env, int64_t n_range, cons
 
 /* Observation of the step on which an env finished (SB3 infos[i]["terminal_observation"]); rows of envs
  * that did not finish on the last step are unspecified.  Only meaningful with auto_reset = 1. */
+/* The handle's own pinned, device-visible staging block of the host-buffer step: actions[n_envs, act_dim], obs[n_envs, obs_dim],
+ * reward[n_envs] in the handle's precision, done[n_envs] u8 - valid for the handle's lifetime.  A caller that writes its actions
+ * THERE and passes these very pointers to mvrl_step / mvrl_step_async / mvrl_step_wait saves the two staging copies of a step (SB3's
+ * numpy buffers are ordinary pageable memory, which is why the copies exist: 25 + 43 MB per step at 1 048 576 6-DoF envs); outputs are
+ * overwritten by the next step. */
+int mvrl_host_buffers(mvrl_handle* h, void** actions, void** obs, void** reward, uint8_t** done);
 int mvrl_get_terminal_obs(mvrl_handle* h, float* obs);
 int mvrl_get_terminal_obs_f64(mvrl_handle* h, double* obs);
 /* k_steps consecutive env steps in one call: actions_dev [k][n][act_dim], obs_dev [k][n][obs_dim], reward_dev [k][n],

@@ -29,7 +29,7 @@ SYMBOLS = [
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
     "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64", "mvrl_vehicle_ops", "mvrl_vehicle_ops_f64", "mvrl_specialize", "mvrl_jit_compile_check",
-    "mvrl_jit_info", "mvrl_jit_compile_check2", "mvrl_jit_child_env", "mvrl_force_components", "mvrl_force_components_f64", "mvrl_mass_solve", "mvrl_mass_solve_f64", "mvrl_observe", "mvrl_observe_f64",
+    "mvrl_jit_info", "mvrl_jit_compile_check2", "mvrl_jit_child_env", "mvrl_force_components", "mvrl_force_components_f64", "mvrl_mass_solve", "mvrl_mass_solve_f64", "mvrl_observe", "mvrl_observe_f64", "mvrl_host_buffers",
     "mvrl_auv_pd_episodes_dev", "mvrl_rollout_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
@@ -117,6 +117,7 @@ def load(path=None):
     lib.mvrl_mass_solve.argtypes = [vp, i64, vp, vp]
     lib.mvrl_mass_solve_f64.argtypes = [vp, i64, vp, vp]
     lib.mvrl_observe.argtypes = [vp, vp]
+    lib.mvrl_host_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.mvrl_observe_f64.argtypes = [vp, vp]
     lib.mvrl_rollout_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.mvrl_auv_pd_episodes_dev.argtypes = [vp, vp, vp, C.c_double, i32, vp, vp, vp]
@@ -180,9 +181,19 @@ class Handle:
         h = C.c_void_p()
         check(self.lib.mvrl_create(C.byref(cfg), C.byref(h)))
         self.h = h
-        self._obs = np.zeros((self.n, self.obs_dim), self.dtype)
-        self._rew = np.zeros(self.n, self.dtype)
-        self._done = np.zeros(self.n, np.uint8)
+        # numpy views of the handle's pinned staging block (mvrl_host_buffers): the step writes its outputs there and reads the
+        # actions from there - no staging copies inside the library
+        pa, po, pr, pd = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self.lib.mvrl_host_buffers(self.h, C.byref(pa), C.byref(po), C.byref(pr), C.byref(pd)), self.h)
+        ct = C.c_double if self.f64 else C.c_float
+
+        def view(ptr, shape, ctype, dtype):
+            cnt = int(np.prod(shape))
+            return np.frombuffer((ctype * cnt).from_address(ptr.value), dtype=dtype).reshape(shape)
+        self._act_in = view(pa, (self.n, self.act_dim), ct, self.dtype)
+        self._obs = view(po, (self.n, self.obs_dim), ct, self.dtype)
+        self._rew = view(pr, (self.n,), ct, self.dtype)
+        self._done = view(pd, (self.n,), C.c_uint8, np.uint8)
 
     def _fn(self, name):
         return getattr(self.lib, name + self._sfx)
@@ -190,6 +201,7 @@ class Handle:
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "h", None):
+            self._act_in = self._obs = self._rew = self._done = None     # views of memory the handle owns
             self.lib.mvrl_destroy(self.h)
             self.h = None
 
@@ -225,17 +237,24 @@ class Handle:
                                      None if ini is None else ini.ctypes.data, obs.ctypes.data), self.h)
         return obs
 
+    def _stage_actions(self, actions):
+        """actions -> the handle's pinned action block (one copy, with dtype conversion if needed); returns its address or None"""
+        if actions is None:
+            return None
+        np.copyto(self._act_in, np.asarray(actions).reshape(self.n, self.act_dim), casting="same_kind")
+        return self._act_in.ctypes.data
+
     def step(self, actions):
-        a = None if actions is None else _real(actions, self.dtype, (self.n, self.act_dim))
-        check(self._fn("mvrl_step")(self.h, None if a is None else a.ctypes.data, self._obs.ctypes.data,
+        """One env step through host buffers.  The returned arrays are views of the handle's pinned staging block: valid until the next
+        step (MarineVecEnv hands out copies)."""
+        check(self._fn("mvrl_step")(self.h, self._stage_actions(actions), self._obs.ctypes.data,
                                     self._rew.ctypes.data, self._done.ctypes.data), self.h)
         return self._obs, self._rew, self._done
 
     def step_async(self, actions):
         if self.f64:
             raise MvrlError("step_async/step_wait are fp32-only; fp64 handles use step()")
-        a = None if actions is None else _f32(actions, (self.n, self.act_dim))
-        check(self.lib.mvrl_step_async(self.h, None if a is None else a.ctypes.data), self.h)
+        check(self.lib.mvrl_step_async(self.h, self._stage_actions(actions)), self.h)
 
     def step_wait(self):
         check(self.lib.mvrl_step_wait(self.h, self._obs.ctypes.data, self._rew.ctypes.data, self._done.ctypes.data),
