@@ -211,13 +211,11 @@ def random_rov_batch(dof, n, steps, seed):
 
 
 # ---- the configuration sweep (tests/test_gpu_parity.py::test_config_fuzz_vs_oracle, tests/audit/fuzz_isolate.py) ----
-# Fixed set-points with arbitrary target pitch send vehicles towards +-90 deg: the attitude kinematics divide by cos(theta)
-# (resources.py:116-132), and past 60 deg they multiply rounding several-fold per sub-step (with ZOH control at h = 0.1 s errors
-# of 1e-4 were seen at cos(theta) = 0.16 .. 0.41, and a drift of 6.6e-5 - just past the jump line - at 0.455).  For the sweep an
-# env pitched beyond 60 deg (1 / cos(theta) > 2) counts as ill-conditioned; the sharp bound (0.05) stays in force in the
-# random-action batches.
+# Rounds 2-3 treated |cos(theta)| < 0.5 as ill-conditioned in the sweep (fixed set-points with arbitrary target pitch send vehicles
+# towards +-90 deg, and past 60 deg the attitude kinematics multiplied the kernels' rounding several-fold per sub-step).  With the binary
+# angles the sweep runs with the SAME sharp bounds as every other test (0.05): over 25 seeds x 24 cases two envs jump without a recorded
+# discontinuity nearby, both in the fixed-set-point x turbulence x ZOH corner, where the fp32 build of the oracle has more of the same.
 FUZZ_BOUNDS = np.array(F32_BOUNDS, float)
-FUZZ_BOUNDS[4] = 0.5
 FUZZ_MAX_DRIFT_SHARE = 0.01
 FUZZ_MAX_BAD_SHARE = 0.015
 
