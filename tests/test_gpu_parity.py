@@ -10,7 +10,7 @@ import pytest
 
 from .conftest import GOLDEN, golden, max_scaled_err
 from .parity_util import (F32_BOUNDS, FUZZ_BOUNDS, FUZZ_MAX_BAD_SHARE, FUZZ_MAX_DRIFT_SHARE, OutlierAudit, fuzz_cases, make_resolver,
-                          random_rov_batch, SMOOTH_TOL_NSUB8)
+                          random_rov_batch)
 from marinevehiclereinforcementlearning_amd import _lib, params as P
 from marinevehiclereinforcementlearning_amd.synthetic import BASE_DT, synthetic_spod
 
@@ -124,7 +124,8 @@ def test_random_batch_vs_fp64_oracle(oracle_mod, dof, mode, n_sub):
         assert max_scaled_err(o_gpu[on], o_ref[on]) < 2 * TOL, s
     print(f"dof={dof} mode={mode} n_sub={n_sub}: median err {med:.1e}; " + audit.report())
     # measured (gpurun_out/r2_margins2.log): 7, 2, 1, 1, 4, 29 of 4096 envs for the six parametrisations
-    budget = {(6, P.CTRL_FAITHFUL, 4): 0.004, (6, P.CTRL_FAITHFUL, 8): 0.016, (6, P.CTRL_FAITHFUL, 2): 0.002}.get((dof, mode, n_sub), 0.001)
+    # twice the measured count of round 4 (4 / 12 / 0 of 4096 at n_sub 4 / 8 / 2, 0-1 elsewhere; rounds 2-3: 7 / 29 / 4)
+    budget = {(6, P.CTRL_FAITHFUL, 4): 0.002, (6, P.CTRL_FAITHFUL, 8): 0.006, (6, P.CTRL_FAITHFUL, 2): 0.001}.get((dof, mode, n_sub), 0.001)
     # envs that drift past 1e-5 without ever jumping: 0.003 % (FAITHFUL, n_sub 4), 0.03 % (n_sub 8), 0.05 % (ZOH) of 65 536 envs
     # (tests/audit/err_quantiles.py, gpurun_out/r2_errq18.log) - bounded at twice the measured share
     audit.assert_explained(max_share=budget, max_smooth_share=0.001 if mode == P.CTRL_ZOH or n_sub == 8 else 0.0005,
