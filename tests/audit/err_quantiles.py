@@ -40,6 +40,16 @@ def main():
     print("  max-error quantiles of the envs that never jumped (50 / 90 / 99 / 99.9 / 99.99 %): " + " ".join(f"{x:.2e}" for x in q))
     print(f"  beyond 1e-5: {int(audit.bad.sum())} ({100 * audit.bad.mean():.3f} %), drifted (<= {SMOOTH_TOL:g}): {int(audit.smooth().sum())} "
           f"({100 * audit.smooth().mean():.4f} %), jumped: {int(audit.jumped.sum())}, unexplained: {int(audit.unexplained().sum())}")
+    # how close to a discontinuity the jumps really were: distance / bound of the NEAREST one, over all envs that jumped - the bounds are sharp
+    # when the bulk sits well below 1 and only the last per cent near or beyond it
+    jm = np.nonzero(audit.jumped)[0]
+    if len(jm):
+        ratio = audit.margin_at_jump[jm] / audit.bounds
+        near = ratio.min(axis=1)
+        which = ratio.argmin(axis=1)
+        print("  jumps: nearest discontinuity at distance / bound  50 %% %.3f  90 %% %.3f  99 %% %.3f  max %.2f;  by kind: " % tuple(np.quantile(near, [0.5, 0.9, 0.99, 1.0]))
+              + ", ".join(f"{nm} {int((which == k).sum())} (90 pct at {np.quantile(near[which == k], 0.9):.2f})" for k, nm in enumerate(
+                  ["pid-increment sign", "thruster dead-band", "wind-up limit", "yaw-error branch", "cos(theta)"]) if (which == k).any()))
     from tests.parity_util import NAMES, ensemble_sensitive, ENSEMBLE_NOISE, ENSEMBLE_NOISE_3DOF
     ENSEMBLE_NOISE = ENSEMBLE_NOISE if dof == 6 else ENSEMBLE_NOISE_3DOF
     un = np.nonzero(audit.unexplained())[0]

@@ -13,10 +13,13 @@ import numpy as np
 
 # fp32 bounds, in the units of oracle.OracleRovEnv.margins.  Calibrated on 6 x 16384 envs x 60 steps (tests/audit/margin_probe.py,
 # gpurun_out/r2_margins*.log): the largest distance seen on an env that jumped off x ~3.
+# Round 4 (binary angles: the kernels' noise is several times smaller): of the 425 jumps of 524 288 envs x 25 steps, 90 % happened within 0.05 x
+# the round-2 bounds of the nearest discontinuity and 99 % within 2.1 x (3-DoF: 0.16 x / 0.34 x; gpurun_out/r4_margins_*.log) - the first two
+# bounds are a third of what they were.
 F32_BOUNDS = np.array([
-    3e-5,    # |e - eOld| / (h x sum_j |J_ij nu_j|) at a zero-dt PID call: how completely the terms of a pose rate cancel; fp32
-             # carries each term to 6e-8 and the increment is a difference of two or four stage slopes
-    3e-4,    # | |rpm| / 300 - 1 |: the dead-band acts on demands of O(1..40 N) whose fp32 error is ~1e-6 x the terms of Ainv b
+    1e-5,    # |e - eOld| / (h x sum_j |J_ij nu_j|) at a zero-dt PID call: how completely the terms of a pose rate cancel; fp32
+             # carries each term to 6e-8 and the increment is a difference of two or four stage slopes   (rounds 2-3: 3e-5)
+    1e-4,    # | |rpm| / 300 - 1 |: the dead-band acts on demands of O(1..40 N) whose fp32 error is ~1e-6 x the terms of Ainv b   (3e-4)
     1e-4,    # | |e| - windup | [m or rad]
     1e-4,    # pi - |yaw error| [rad]
     5e-2,    # |cos(theta)|: 1 / cos(theta) amplifies fp32 rounding 20 x and more
