@@ -36,11 +36,14 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "c4"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 250
+    n_sub = int(os.environ.get("MVRL_AUDIT_NSUB", "4"))                      # other parametrisations of the same audit
+    mode = P.CTRL_ZOH if os.environ.get("MVRL_AUDIT_ZOH") else P.CTRL_FAITHFUL
+    kw = dict(n_substeps=n_sub, control_mode=mode)
     dof = 3 if which == "c2" else 6
     use_flow = which == "c4"
     npos = 3 if dof == 6 else 2
     model = "rov6" if dof == 6 else "rov3"
-    h = _lib.Handle(P.make_config(model, n, auto_reset=False, max_steps=10 ** 9, use_flow=use_flow, seed=12345))
+    h = _lib.Handle(P.make_config(model, n, auto_reset=False, max_steps=10 ** 9, use_flow=use_flow, seed=12345, **kw))
     ft = None
     if use_flow:
         flow = ReconstructedFlow.synthetic(n_modes=8, n_time=2000)
@@ -54,10 +57,10 @@ def main():
     path = st[5 * dof:5 * dof + 2 * npos].T
     init = np.concatenate([path, sp[:, npos:]], axis=1).astype(np.float64)
     toff = st[-2].copy()
-    ref = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft)
-    low = orc.OracleRovEnv(dof, n, "f32", max_steps=10 ** 9, flow=ft)
-    flo = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft)
-    fla = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft)      # ... the same floor with the ANGLES left exact (what binary angles buy)
+    ref = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft, **kw)
+    low = orc.OracleRovEnv(dof, n, "f32", max_steps=10 ** 9, flow=ft, **kw)
+    flo = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft, **kw)
+    fla = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft, **kw)      # ... the same floor with the ANGLES left exact (what binary angles buy)
     ref.reset(init, toffset=toff)
     low.reset(init, toffset=toff)
     flo.reset(init, toffset=toff)
@@ -65,7 +68,7 @@ def main():
     ang = [3, 4, 5] if dof == 6 else [2]
     a_gpu, a_low, a_flo, a_fla = (OutlierAudit(n, 1e-5, dof=dof) for _ in range(4))
     rng = np.random.default_rng(2024)
-    print(f"# whole-episode audit {which}: {h.variant}, {n} envs x {steps} steps, dt 0.2, n_sub 4, FAITHFUL, random resets + uniform actions, vs the fp64 oracle")
+    print(f"# whole-episode audit {which}: {h.variant}, {n} envs x {steps} steps, dt 0.2, n_sub {n_sub}, {'ZOH' if mode == P.CTRL_ZOH else 'FAITHFUL'}, random resets + uniform actions, vs the fp64 oracle")
     print("# step | HIP fp32 kernel: beyond 1e-5 [%]  drifted  jumped(explained)  jumped(beyond the bounds)  median err  q99 of calm envs "
           "| fp32 build of the oracle: beyond 1e-5 [%]  drifted  jumped  beyond the bounds  median err "
           "| fp64 oracle with fp32 state between steps (floor): beyond 1e-5 [%]  median err "
