@@ -165,6 +165,13 @@ typedef struct mvrl_config {
 
 typedef struct mvrl_handle mvrl_handle;
 
+/* The configuration the reference's constructors amount to - BlueROV2Heavy6DoFEnv() / BlueROV2Heavy3DoFEnv() / AuvEnv() with their default
+ * arguments (6DoF.py:83-218, :445-465; 3DoF.py:26-126, :375-395; verySimpleAuv.py:76-127): every constant of the three parameter blocks
+ * (incl. M^-1 and pinv(A), which a C caller would otherwise have to compute), dt 0.2 / 0.02 s, 250-step episodes, and this build's choices
+ * for what the reference does not have: RK4 with 4 sub-steps, PID at every stage (FAITHFUL), fp32, auto-reset on, turbulence for AuvEnv
+ * only, device 0, seed 0.  Edit the fields you want to differ, then mvrl_create.  (Python: params.make_config is the same thing.) */
+int mvrl_default_config(int32_t model, int64_t n_envs, mvrl_config* out);
+
 /* ---- introspection ------------------------------------------------------------------------- */
 int mvrl_abi_version(void);
 /* number of visible HIP devices (0 when none; never fails) */

@@ -29,7 +29,7 @@ SYMBOLS = [
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
     "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64", "mvrl_vehicle_ops", "mvrl_vehicle_ops_f64", "mvrl_specialize", "mvrl_jit_compile_check",
-    "mvrl_jit_info", "mvrl_jit_compile_check2", "mvrl_jit_child_env", "mvrl_force_components", "mvrl_force_components_f64", "mvrl_mass_solve", "mvrl_mass_solve_f64", "mvrl_observe", "mvrl_observe_f64", "mvrl_host_buffers",
+    "mvrl_jit_info", "mvrl_jit_compile_check2", "mvrl_jit_child_env", "mvrl_force_components", "mvrl_force_components_f64", "mvrl_mass_solve", "mvrl_mass_solve_f64", "mvrl_observe", "mvrl_observe_f64", "mvrl_host_buffers", "mvrl_default_config",
     "mvrl_auv_pd_episodes_dev", "mvrl_rollout_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
@@ -118,6 +118,7 @@ def load(path=None):
     lib.mvrl_mass_solve_f64.argtypes = [vp, i64, vp, vp]
     lib.mvrl_observe.argtypes = [vp, vp]
     lib.mvrl_host_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.mvrl_default_config.argtypes = [i32, i64, vp]
     lib.mvrl_observe_f64.argtypes = [vp, vp]
     lib.mvrl_rollout_dev.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     lib.mvrl_auv_pd_episodes_dev.argtypes = [vp, vp, vp, C.c_double, i32, vp, vp, vp]

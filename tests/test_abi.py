@@ -196,3 +196,33 @@ def test_library_does_not_link_hiprtc_at_load_time(lib):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
     needed = [ln for ln in out.splitlines() if "NEEDED" in ln]
     assert needed and not any("hiprtc" in ln for ln in needed), needed
+
+
+def test_default_config_equals_make_config(lib):
+    """mvrl_default_config (what a C caller starts from) fills the very bytes params.make_config does, for all three models:
+    the reference's default constants incl. M^-1 and pinv(A), generated from params.py at build time (csrc/gen/mvrl_defaults.inc)."""
+    for name, model in P.MODEL_NAMES.items():
+        c = P.Config()
+        assert lib.mvrl_default_config(model, 4096, C.byref(c)) == 0
+        assert bytes(c) == bytes(P.make_config(name, 4096)), name
+    assert lib.mvrl_default_config(7, 1, C.byref(P.Config())) != 0 and lib.mvrl_default_config(2, 1, None) != 0
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "step_rov6")
+    pkg = os.path.join(REPO, "marinevehiclereinforcementlearning_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "step_rov6.c"),
+                           "-L", pkg, "-lmvrl", f"-Wl,-rpath,{pkg}", "-o", exe])
+    return exe
+
+
+def test_c_example_builds_against_the_header_and_fails_loudly_without_a_gpu(lib, tmp_path):
+    """examples/step_rov6.c: plain C against include/mvrl.h + libmvrl.so (no Python, no torch).  Without a HIP device it must say so and
+    exit 2 - no CPU fallback."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    if lib.mvrl_device_count() > 0:
+        pytest.skip("a GPU is present: tests/test_gpu_api.py runs the example for real")
+    r = subprocess.run([exe, "64", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "no HIP device" in r.stderr and "step" not in r.stdout

@@ -636,3 +636,32 @@ def test_host_buffer_step_with_the_callers_own_arrays_equals_the_staging_block_p
         assert np.array_equal(o, ob) and np.array_equal(r, rew_b) and np.array_equal(d, done_b), k
     assert np.array_equal(a.get_state(raw=True).view(np.uint32), b.get_state(raw=True).view(np.uint32))    # bit patterns (a binary angle may read as a NaN)
     a.close(); b.close()
+
+
+def test_c_example_runs_and_agrees_with_the_python_path(tmp_path):
+    """examples/step_rov6.c (plain C: mvrl_default_config -> mvrl_create -> mvrl_host_buffers -> mvrl_reset / mvrl_step) against the same
+    steps through `Handle`: first env's observations and the checksum over all envs, step by step."""
+    import re
+    import subprocess
+    from .test_abi import _build_c_example
+    n, steps = 1024, 6
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe, str(n), str(steps)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("step")]
+    assert len(lines) == steps and "rov6/baked/faithful" in r.stdout
+    h = _lib.Handle(P.make_config("rov6", n, seed=7))
+    h.reset()
+    s = np.uint32(12345)
+    for t in range(steps):
+        a = np.empty(n * 6, np.float32)
+        x = int(s)
+        for i in range(n * 6):                                     # the example's LCG
+            x = (x * 1664525 + 1013904223) & 0xFFFFFFFF
+            a[i] = np.float32(x >> 8) * np.float32(2.0 / 16777216.0) - np.float32(1.0)
+        s = np.uint32(x)
+        o, _, d = h.step(a.reshape(n, 6))
+        nums = [float(v) for v in re.findall(r"-?\d+\.\d+", lines[t])]
+        assert np.allclose(nums[:9], o[0], atol=1.5e-6), (t, nums[:9], o[0])
+        assert abs(nums[9] - float(o.astype(np.float64).sum())) < 1e-3 * max(1.0, abs(nums[9])), (t, nums[9])
+    h.close()
