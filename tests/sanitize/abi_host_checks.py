@@ -51,12 +51,18 @@ for call in (lambda: lib.mvrl_step(None, one, one, one, one), lambda: lib.mvrl_r
              lambda: lib.mvrl_get_state(None, one, 64), lambda: lib.mvrl_set_state(None, one, 64), lambda: lib.mvrl_specialize(None),
              lambda: lib.mvrl_jit_info(None, None), lambda: lib.mvrl_enable_aux(None, 1), lambda: lib.mvrl_synchronize(None),
              lambda: lib.mvrl_step_dev(None, None, None, None, None, None), lambda: lib.mvrl_jit_child_env(None, 0),
-             lambda: lib.mvrl_force_components(None, 1, one, one, one, one), lambda: lib.mvrl_derivs(None, 1, *([one] * 10))):
+             lambda: lib.mvrl_force_components(None, 1, one, one, one, one), lambda: lib.mvrl_derivs(None, 1, *([one] * 10)),
+             lambda: lib.mvrl_mass_solve(None, 1, one, one), lambda: lib.mvrl_observe(None, one),
+             lambda: lib.mvrl_host_buffers(None, None, None, None, None), lambda: lib.mvrl_default_config(9, 1, C.byref(P.Config())),
+             lambda: lib.mvrl_default_config(2, 1, None)):
     assert call() != 0
 assert lib.mvrl_model_dims(7, None, None, None, None) != 0 and lib.mvrl_aux_dim(9) < 0
 a, o_, i_, w = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
 for model in (0, 1, 2):
     assert lib.mvrl_model_dims(model, C.byref(a), C.byref(o_), C.byref(i_), C.byref(w)) == 0
+for name, model in P.MODEL_NAMES.items():       # the generated default blocks, copied through the ABI
+    c = P.Config()
+    assert lib.mvrl_default_config(model, 77, C.byref(c)) == 0 and bytes(c) == bytes(P.make_config(name, 77))
 lib.mvrl_destroy(None)
 assert lib.mvrl_variant(None) == b""
 
