@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from .conftest import GOLDEN, golden, max_scaled_err
-from .parity_util import (F32_BOUNDS, FUZZ_BOUNDS, FUZZ_MAX_BAD_SHARE, FUZZ_MAX_DRIFT_SHARE, OutlierAudit, fuzz_cases, make_resolver,
+from .parity_util import (FUZZ_BOUNDS, FUZZ_MAX_BAD_SHARE, FUZZ_MAX_DRIFT_SHARE, OutlierAudit, fuzz_cases, make_resolver,
                           random_rov_batch)
 from marinevehiclereinforcementlearning_amd import _lib, params as P
 from marinevehiclereinforcementlearning_amd.synthetic import BASE_DT, synthetic_spod

@@ -3,7 +3,6 @@
 (null) stream, on a torch side stream, and on a non-blocking HIP stream.   python tools/stream_probe.py [workload-envs] [K]"""
 import os
 import sys
-import time
 
 import torch
 
