@@ -8,7 +8,7 @@ One "step" = one env step of every environment of the batch: one launch of the f
 independent, so each chain's next launch only waits for its own previous one and the other chain's kernel covers the
 launch gap, ramp and tail).  Timing: after a stated pre-warm (>= --prewarm-s seconds of the same steps, so that the
 shader clock has settled) and W warm-up steps, the K-step timed region - bracketed by barrier + synchronize - is repeated
---repeats times (default: as many as give each launch plan >= 1 s of timed work, 11 .. 1001); `ms_per_step` / `value` are the
+--repeats times (default: as many as give each launch plan >= 2 s of timed work, 11 .. 1001); `ms_per_step` / `value` are the
 MEDIAN repeat (max over ranks per repeat); the repeats (or 33 order statistics of them) are in the line.
 `value` is the sharded hot path with outputs left in each rank's HBM (the same thing at every N); for N > 1 the
 RCCL gather of observations/rewards/dones to rank 0 that BASELINE.json's 8-GPU config names is run and timed over the
@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--repeats", type=int, default=0, help="the K-step timed region is repeated this many times; the median is reported "
                     "(short regions swing by +-4 %% with the power controller's state: see timing.ms_per_step_repeats).  0 (default) = as "
-                    "many as make >= 1 s of timed GPU work per launch plan, at least 11, at most 1001: a 20-step region lasts 2 ms")
+                    "many as make >= 2 s of timed GPU work per launch plan, at least 11, at most 1001: a 20-step region lasts 2 ms")
     ap.add_argument("--prewarm-s", type=float, default=0.4, help="seconds of untimed steps before the warm-up (clock settling)")
     ap.add_argument("--chains", type=int, default=2, help="independent lane-range chains per step (1 = one launch per step on one stream)")
     ap.add_argument("--launch", default="auto", choices=["auto", "chains", "single"],
@@ -431,9 +431,9 @@ def main():
     by_plan = {pl: [] for pl in plans}
     n_repeats = args.repeats
     if n_repeats <= 0:
-        # automatic: the pre-warm measured what a step takes here; repeat the K-step region until each plan has >= 1 s of timed
-        # work behind its median (K = 2000: 11 repeats; the driver's K = 20: ~450 regions of 2.2 ms instead of 11 of them)
-        n_repeats = int(min(1001, max(11, 1.0 / max(1e-9, K * step_us_estimate * 1e-6))))
+        # automatic: the pre-warm measured what a step takes here; repeat the K-step region until each plan has >= 2 s of timed
+        # work behind its median (K = 2000: 11 repeats; the driver's K = 20: ~900 regions of 2.2 ms instead of 11 of them)
+        n_repeats = int(min(1001, max(11, 2.0 / max(1e-9, K * step_us_estimate * 1e-6))))
         n_repeats += 1 - n_repeats % 2          # odd: the median is a repeat that was measured
         if world > 1:                           # every rank must run the same number of regions (they contain barriers)
             t_rep = torch.tensor([n_repeats], dtype=torch.int64, device=dev)
