@@ -99,10 +99,10 @@ struct AuvStepOut {
 // PD-episode kernel, so both run the same arithmetic.
 template <bool FLOW>
 __device__ __forceinline__ void auv_step_core(const AuvDev& p, const FlowDev& fl, AuvLane& s, float a0, float a1, float a2,
-                                              float dt, int max_steps, AuvStepOut& out) {
+                                              float dt, double dt64, int max_steps, AuvStepOut& out) {
     const bool cyl = p.n_wp > 0;
     s.istep += 1;                                  // verySimpleAuv.py:266
-    const float time = (float)s.istep * dt;        // :267
+    // time = iStep * dt (:267): only the turbulence lookup reads it, and forms it in fp64 from the step count (flow_time_index)
     const bool time_up = s.istep >= max_steps;     // :270-272
     bool done = time_up;
     const int slot = (s.istep - 1 + s.phase) % 10; // recentActions.appendleft (:275) as a ring starting at slot `phase`
@@ -118,7 +118,7 @@ __device__ __forceinline__ void auv_step_core(const AuvDev& p, const FlowDev& fl
     float sn, c;
     sincos_f32(s.psi, sn, c);
     float2 cur = make_float2(0.f, 0.f);
-    if (FLOW) cur = flow_interp_uv(fl, time + s.toff, s.x, s.y);                            // :291
+    if (FLOW) cur = flow_interp_uv(fl, s.istep, dt64, s.toff, s.x, s.y);                    // :291
     const float dvx = s.vx - cur.x, dvy = s.vy - cur.y;
     const float vr0 = c * dvx + sn * dvy, vr1 = -sn * dvx + c * dvy;                        // :298 (pinv(J) = J^T)
     const float Fh0 = (p.xu * s.mu[5] + p.xuu * s.mu[2] * fabsf(vr0)) * vr0;                // :303-307
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
     const float* ap = io.actions + (size_t)i * 3;
     const float a0 = ap[0], a1 = ap[1], a2 = ap[2];
     AuvStepOut out;
-    auv_step_core<FLOW>(p, fl, s, a0, a1, a2, io.dt, io.max_steps, out);
+    auv_step_core<FLOW>(p, fl, s, a0, a1, a2, io.dt, io.dt64, io.max_steps, out);
     // the kernel body below keeps its historical local names
     float x = s.x, y = s.y, psi = s.psi, vx = s.vx, vy = s.vy, r = s.r, tgt = s.tgt, tx = s.tx, ty = s.ty;
     float herr_o = s.herr_o, perr_ox = s.perr_ox, perr_oy = s.perr_oy;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_step_kernel(const AuvDev p, co
 // (pd_policy_kernel + auv_step_kernel), so the two agree to fp32 rounding of the return sum.
 template <bool FLOW>
 __global__ __launch_bounds__(MVRL_BLOCK) void auv_pd_episode_kernel(const AuvDev p, const FlowDev fl, float* __restrict__ state,
-                                                                    int64_t n, float dt, int max_steps, int n_steps,
+                                                                    int64_t n, double dt64, int max_steps, int n_steps,
                                                                     float inv_pdt, float p0, float p1, float p2, float d0,
                                                                     float d1, float d2, float* __restrict__ returns,
                                                                     int32_t* __restrict__ lengths) {
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_pd_episode_kernel(const AuvDev
             old[k] = xk;
         }
         AuvStepOut out;
-        auv_step_core<FLOW>(p, fl, s, a[0], a[1], a[2], dt, max_steps, out);
+        auv_step_core<FLOW>(p, fl, s, a[0], a[1], a[2], (float)dt64, dt64, max_steps, out);
         ret += out.reward;
         len += 1;
 #pragma unroll
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_pd_episode_kernel(const AuvDev
 #undef ST
 }
 
-hipError_t launch_auv_pd_episodes(const AuvDev& p, const FlowDev& fl, bool flow, float* state, int64_t n, float dt, int max_steps,
+hipError_t launch_auv_pd_episodes(const AuvDev& p, const FlowDev& fl, bool flow, float* state, int64_t n, double dt, int max_steps,
                                   int n_steps, float policy_dt, const float* P, const float* D, float* returns, int32_t* lengths,
                                   hipStream_t stream) {
     dim3 grid((unsigned)((n + MVRL_BLOCK - 1) / MVRL_BLOCK)), block(MVRL_BLOCK);
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(MVRL_BLOCK) void auv_rollout_kernel(const AuvDev p,
     for (int k = 0; k < io.k_steps; k++) {
         const float* ap = io.actions + ((size_t)k * n + i) * 3;
         AuvStepOut out;
-        auv_step_core<FLOW>(p, fl, s, ap[0], ap[1], ap[2], io.dt, io.max_steps, out);
+        auv_step_core<FLOW>(p, fl, s, ap[0], ap[1], ap[2], io.dt, io.dt64, io.max_steps, out);
         io.reward[(size_t)k * n + i] = out.reward;
         io.done[(size_t)k * n + i] = out.done ? (out.time_up ? 3 : 1) : 0;
         if (out.done && io.auto_reset) {

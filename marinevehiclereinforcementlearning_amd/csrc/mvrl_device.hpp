@@ -232,6 +232,8 @@ struct FlowDev {
     const float4* table;
     int n_t, n_y, n_x;
     float inv_dt, inv_dx, inv_dy;
+    // the sample TIME is formed in fp64 in both builds (flow_time_index): 1 / dt of the table and 1 / (2 (n_t - 1)) as host-side doubles
+    double inv_dt64, inv_period2;
     float t_quarter;      // flow.time[n_t // 4]  (verySimpleAuv.py:245)
     // 0: ReconstructedFlow.interp as it is (AuvEnv, mvrl_flow_interp): indices clamped, weights not - linear EXTRAPOLATION outside
     //    the table.  AuvEnv ends an episode 1 m from the origin after at most 5 s, so it never gets far outside.
@@ -251,20 +253,35 @@ struct FlowTap {
     float2 c000, c001, c010, c011, c100, c101, c110, c111;
     float ft, fx, fy;
 };
-__device__ __forceinline__ FlowTap flow_gather(const FlowDev& f, float time, float x, float y) {
+// Sample time in table units, split into slice index and fraction - in fp64 SCALARS of the lane, whatever the build's precision.
+// The env's time is an integer step count times the host's fp64 dt (verySimpleAuv.py:266-267, 6DoF.py:533-534) plus the episode's
+// offset; at step 250 of a rigid-body episode time / dt_table is ~2 700, whose fp32 ulp is 2.4e-4 of a slice: formed in fp32 the
+// sample time was off by ~5e-5 slices, i.e. 1e-7 .. 6e-7 m/s of current per step (VERDICT r4 "weak 2") - several times the rounding
+// of a velocity word, injected every step.  In fp64 the index is exact and the fraction is rounded once, to fp32, at its own size.
+__device__ __forceinline__ void flow_time_index(const FlowDev& f, int istep, double dt64, float toff, int& kk, float& ft) {
+#if defined(MVRL_FLOW_TIME_F32) && !MVRL_F64   /* attribution build only (tests/audit/episode_audit.py): the round-4 fp32 sample time */
+    double tt = (double)(((float)istep * (float)dt64 + toff) * f.inv_dt);
+#else
+    double tt = ((double)istep * dt64 + (double)toff) * f.inv_dt64;
+#endif
+    if (f.bounded) {   // wave-uniform: triangle wave over [0, n_t - 1] (see FlowDev::bounded)
+        const double per = (double)(f.n_t - 1);
+        const double m = tt - 2.0 * per * floor(tt * f.inv_period2);   // [0, 2 per)
+        tt = per - fabs(m - per);
+    }
+    kk = min(f.n_t - 2, max(0, (int)floor(tt)));
+    ft = (float)(tt - (double)kk);
+}
+__device__ __forceinline__ FlowTap flow_gather(const FlowDev& f, int kk, float ft, float x, float y) {
     FlowTap g;
-    float tt = time * f.inv_dt, xx = x * f.inv_dx, yy = y * f.inv_dy;
+    float xx = x * f.inv_dx, yy = y * f.inv_dy;
     if (f.bounded) {   // wave-uniform
-        const float per = (float)(f.n_t - 1);
-        const float m = tt - 2.f * per * floorf(tt / (2.f * per));   // [0, 2 per)
-        tt = per - fabsf(m - per);                                   // triangle wave over [0, per]
         xx = clampf(xx, 0.f, (float)(f.n_x - 1));
         yy = clampf(yy, 0.f, (float)(f.n_y - 1));
     }
-    int kk = min(f.n_t - 2, max(0, (int)floorf(tt)));
     int ii = min(f.n_x - 2, max(0, (int)floorf(xx)));
     int jj = min(f.n_y - 2, max(0, (int)floorf(yy)));
-    g.ft = tt - (float)kk; g.fx = xx - (float)ii; g.fy = yy - (float)jj;
+    g.ft = ft; g.fx = xx - (float)ii; g.fy = yy - (float)jj;
     // one line: (x0, x1) of row y0 at t0 | row y1 at t0 | row y0 at t1 | row y1 at t1
     const float4* q = f.table + (((size_t)kk * f.n_y + jj) * f.n_x + ii) * 4;
     const float4 a = q[0], b = q[1], c = q[2], d = q[3];
@@ -282,8 +299,11 @@ __device__ __forceinline__ float2 flow_combine(const FlowTap& g) {
     float v1 = wy0 * (g.c100.y * wx0 + g.c101.y * fx) + fy * (g.c110.y * wx0 + g.c111.y * fx);
     return make_float2(u0 * wt0 + u1 * ft, v0 * wt0 + v1 * ft);
 }
-__device__ __forceinline__ float2 flow_interp_uv(const FlowDev& f, float time, float x, float y) {
-    return flow_combine(flow_gather(f, time, x, y));
+__device__ __forceinline__ float2 flow_interp_uv(const FlowDev& f, int istep, double dt64, float toff, float x, float y) {
+    int kk;
+    float ft;
+    flow_time_index(f, istep, dt64, toff, kk, ft);
+    return flow_combine(flow_gather(f, kk, ft, x, y));
 }
 
 // ---- device mirrors of the model constants (fp32) -------------------------------------------------
@@ -418,6 +438,7 @@ struct StepIO {
     int fixed_sp;
     int auto_reset;
     float dt;
+    double dt64;            // the host's dt unrounded: the turbulence sample time is istep * dt64 (flow_time_index)
     int k_steps;            // > 1: fused multi-step launch (actions / obs / reward / done are [k_steps][n][...])
     // lanes [lane0, lane_end) of the n-lane batch are stepped by this launch (mvrl_step_range_dev: independent chains of
     // sub-batches on their own streams); every array is still indexed by the lane's position in the whole batch

@@ -29,7 +29,7 @@ hipError_t launch_rov3_reset(const Rov3Dev* p_dev, float* state, int64_t n, cons
                              uint64_t seed, int64_t env_offset, float t_quarter, hipStream_t stream);
 
 hipError_t launch_auv_step(const AuvDev& p, const StepIO& io, const FlowDev& fl, bool flow, hipStream_t stream);
-hipError_t launch_auv_pd_episodes(const AuvDev& p, const FlowDev& fl, bool flow, float* state, int64_t n, float dt, int max_steps,
+hipError_t launch_auv_pd_episodes(const AuvDev& p, const FlowDev& fl, bool flow, float* state, int64_t n, double dt, int max_steps,
                                   int n_steps, float policy_dt, const float* P, const float* D, float* returns, int32_t* lengths,
                                   hipStream_t stream);
 hipError_t launch_auv_reset(const AuvDev& p, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,

@@ -280,7 +280,12 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     const bool first = (istep == 0);
     istep += 1;
     FlowTap tap;
-    if (FLOW) tap = flow_gather(fl, (float)istep * io.dt + toff, y[0], y[1]);
+    if (FLOW) {   // the sample time in fp64 (flow_time_index)
+        int kk;
+        float ft;
+        flow_time_index(fl, istep, io.dt64, toff, kk, ft);
+        tap = flow_gather(fl, kk, ft, y[0], y[1]);
+    }
     // error coordinates (see rov6_step_kernel): the RK4 loop integrates z = setPoint - pose, which starts the step at a * scale
     // (fixed set-point: z = pose_start - pose, starting at 0, and the controller adds e0 = setPoint - pose_start)
     const bool fixed = io.fixed_sp != 0;

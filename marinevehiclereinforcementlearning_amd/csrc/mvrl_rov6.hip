@@ -81,7 +81,7 @@ __device__ __forceinline__ void pid6(PP p, const float* z, Pid6& s, float half_d
         for (int i = 0; i < 5; i++) e[i] += e0[i];
         z5 += e0[5];
     }
-#if !MVRL_F64 && !defined(MVRL_NO_YAW_INC)
+#if !defined(MVRL_NO_YAW_INC)
     // Yaw error (resources.angleError, resources.py:75-95).  Inside an env step the set-point is constant, so the error of
     // this call is the previous call's minus the yaw increment, wrapped back into [-pi, pi) when it leaves: 7 instructions
     // instead of the 14 of a fresh range reduction plus the branch-consistency test - and the PID's difference e - eOld is
@@ -105,7 +105,7 @@ __device__ __forceinline__ void pid6(PP p, const float* z, Pid6& s, float half_d
     // compares) decides whether the six per-axis compare-and-selects run at all.  Same result as the reference's rule in every
     // case; the fixed-set-point flavour, whose attitude errors sit beyond the limit all the time, keeps the plain form.
     bool windup_any = true;
-#if !MVRL_F64 && !defined(MVRL_NO_WINDUP_VOTE)
+#if !defined(MVRL_NO_WINDUP_VOTE)
     if (!fixed && p->windup[0] == p->windup[1] && p->windup[1] == p->windup[2] && p->windup[3] == p->windup[4] && p->windup[4] == p->windup[5]) {
         const float m_pos = fmaxf(fmaxf(fabsf(e[0]), fabsf(e[1])), fabsf(e[2])), m_ang = fmaxf(fmaxf(fabsf(e[3]), fabsf(e[4])), fabsf(e[5]));
         windup_any = __any((m_pos > p->windup[0]) || (m_ang > p->windup[3])) != 0;
@@ -360,10 +360,28 @@ __device__ __forceinline__ Trig6 trig6_err(const SP& sps, const float* z) {
 // the RHS has 24 more registers.  That takes the kernel from 156 to <= 128 VGPRs = FOUR resident waves per SIMD instead
 // of three; the SIMD's issue slots rotate over 1, 2, 4 or 8 wave slots, so a fourth wave is worth more than a third
 // (tools/valu_dep.hip).  33 LDS instructions per sub-step against ~1450 VALU.
-#if !MVRL_F64 && !defined(MVRL_NO_PARK)
+#if !defined(MVRL_NO_PARK)
 #define MVRL_PARK_ON 1
+// The tiles are made of 16-byte vectors (one ds_read/write_b128 per lane, consecutive lanes 16 B apart: conflict-free): four fp32
+// values or two fp64 values each.
+#if MVRL_F64
+typedef double2 park_vec;
+#define MVRL_PARK_PER 2
+#define MVRL_PARK_LD(dst, v, q) do { (dst)[q] = (v).x; (dst)[(q) + 1] = (v).y; } while (0)
+#define MVRL_PARK_ST(v, src, q) do { (v).x = (src)[q]; (v).y = (src)[(q) + 1]; } while (0)
+#else
+typedef float4 park_vec;
+#define MVRL_PARK_PER 4
+#define MVRL_PARK_LD(dst, v, q) do { (dst)[q] = (v).x; (dst)[(q) + 1] = (v).y; (dst)[(q) + 2] = (v).z; (dst)[(q) + 3] = (v).w; } while (0)
+#define MVRL_PARK_ST(v, src, q) do { (v).x = (src)[q]; (v).y = (src)[(q) + 1]; (v).z = (src)[(q) + 2]; (v).w = (src)[(q) + 3]; } while (0)
+#endif
+#define MVRL_PARK_V12 (12 / MVRL_PARK_PER)   /* vectors per parked 12-vector */
+#define MVRL_PARK_V8 (8 / MVRL_PARK_PER)     /* vectors per SpStore (6 values + 2 spare words) */
 #ifdef MVRL_JIT_MIN_WAVES   /* mvrl_specialize: literal constants need no SGPR headroom; the dense form is tried at 4 waves first */
 #define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, MVRL_JIT_MIN_WAVES)
+#elif MVRL_F64
+// fp64: twice the registers per value - TWO waves per SIMD (256 registers each, accumulation registers included)
+#define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, 2)
 #else
 // Four waves per SIMD (128 VGPRs) for the literal-constant flavour; the flavours that read constants at run time keep them in
 // SGPRs, of which a wave has ~100, and at 128 VGPRs the excess is parked in VGPR lanes or scratch (r3: 19-28 SGPR spills, 12 B of
@@ -373,51 +391,64 @@ __device__ __forceinline__ Trig6 trig6_err(const SP& sps, const float* z) {
 #endif
 #define MVRL_STEP_BOUNDS6 __launch_bounds__(MVRL_STEP_BLOCK, SYM ? (same_type<PP, const Rov6Baked*>::value ? 4 : MVRL_RT_WAVES) : 2)
 #endif
-// LDS per block = 10 KB although the parked tiles need 6: 160 KB / 10 KB = 16 one-wave blocks per CU = exactly four waves
+// LDS per block = 10 KB (fp32) although the parked tiles need 6: 160 KB / 10 KB = 16 one-wave blocks per CU = exactly four waves
 // per SIMD.  A kernel instance that happens to need <= 96 VGPRs would otherwise get a FIFTH wave, and five waves rotate
-// over eight issue slots (tools/valu_dep.hip).
+// over eight issue slots (tools/valu_dep.hip).  fp64: 20 KB = eight blocks per CU = the two waves per SIMD of its register budget.
 #ifndef MVRL_PARK_FLOAT4S
-#define MVRL_PARK_FLOAT4S 640
+#define MVRL_PARK_FLOAT4S (640 * (4 / MVRL_PARK_PER))
 #endif
 struct Park12 {
-    volatile float4* base;   // [3][MVRL_STEP_BLOCK]
+    volatile park_vec* base;   // [MVRL_PARK_V12][MVRL_STEP_BLOCK]
     __device__ __forceinline__ void put(const float* v) const {
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            float4 t; t.x = v[4 * j]; t.y = v[4 * j + 1]; t.z = v[4 * j + 2]; t.w = v[4 * j + 3];
-            const_cast<float4&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]) = t;
+        for (int j = 0; j < MVRL_PARK_V12; j++) {
+            park_vec t;
+            MVRL_PARK_ST(t, v, MVRL_PARK_PER * j);
+            const_cast<park_vec&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]) = t;
         }
         asm volatile("" ::: "memory");   // no store-to-load forwarding across the parking: the value must leave its registers
     }
     __device__ __forceinline__ void get(float* v) const {
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const float4 t = const_cast<const float4&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]);
-            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        for (int j = 0; j < MVRL_PARK_V12; j++) {
+            const park_vec t = const_cast<const park_vec&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]);
+            MVRL_PARK_LD(v, t, MVRL_PARK_PER * j);
         }
     }
 };
 // The set-point of the step: needed inside the RK4 loop only by lanes that take a full sincos (stage_trig) and after it (pose
 // = set-point - error, observation) - six registers the right-hand side can use instead.
 struct SpStore {
-    volatile float4* base;   // [2][MVRL_STEP_BLOCK]
-    // x0, x1: the two spare words of the second float4 (the step's binary start angles ride there, put_extra / get_extra)
+    volatile park_vec* base;   // [MVRL_PARK_V8][MVRL_STEP_BLOCK]
+    // x0, x1: the two spare words behind the six values (the step's binary start angles ride there, put_extra / get_extra)
     __device__ __forceinline__ void put(const float* sp, float x0 = 0.f, float x1 = 0.f) const {
-        float4 a, b; a.x = sp[0]; a.y = sp[1]; a.z = sp[2]; a.w = sp[3]; b.x = sp[4]; b.y = sp[5]; b.z = x0; b.w = x1;
-        const_cast<float4&>(base[threadIdx.x]) = a;
-        const_cast<float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]) = b;
+        const float w[8] = {sp[0], sp[1], sp[2], sp[3], sp[4], sp[5], x0, x1};
+#pragma unroll
+        for (int j = 0; j < MVRL_PARK_V8; j++) {
+            park_vec t;
+            MVRL_PARK_ST(t, w, MVRL_PARK_PER * j);
+            const_cast<park_vec&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]) = t;
+        }
         asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void get_extra(float& x0, float& x1) const {
         asm volatile("" ::: "memory");
-        const float4 b = const_cast<const float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]);
-        x0 = b.z; x1 = b.w;
+        float w[MVRL_PARK_PER];
+        const park_vec b = const_cast<const park_vec&>(base[(MVRL_PARK_V8 - 1) * MVRL_STEP_BLOCK + threadIdx.x]);
+        MVRL_PARK_LD(w, b, 0);
+        x0 = w[MVRL_PARK_PER - 2]; x1 = w[MVRL_PARK_PER - 1];
     }
     __device__ __forceinline__ void get(float* sp) const {
         asm volatile("" ::: "memory");
-        const float4 a = const_cast<const float4&>(base[threadIdx.x]), b = const_cast<const float4&>(base[MVRL_STEP_BLOCK + threadIdx.x]);
-        sp[0] = a.x; sp[1] = a.y; sp[2] = a.z; sp[3] = a.w; sp[4] = b.x; sp[5] = b.y;
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < MVRL_PARK_V8; j++) {
+            const park_vec t = const_cast<const park_vec&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]);
+            MVRL_PARK_LD(w, t, MVRL_PARK_PER * j);
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) sp[q] = w[q];
     }
 };
 #else
@@ -442,7 +473,7 @@ template <bool ERRC = false, class SP = NoSp>
 __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, const float* d, const SP& sp = SP()) {
     // ERRC: yt is in error coordinates (the FAITHFUL / ZOH loops of the step kernel): absolute angles = set-point - yt
 #define MVRL_FULL_TRIG() (ERRC ? trig6_err(sp, yt) : trig6(yt))
-#if MVRL_F64 || defined(MVRL_FULL_STAGE_TRIG)
+#if defined(MVRL_FULL_STAGE_TRIG)
     return MVRL_FULL_TRIG();
 #else
     const float m = fmaxf(fmaxf(fabsf(d[3]), fabsf(d[4])), fabsf(d[5]));
@@ -454,10 +485,18 @@ __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, con
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float r = d[3 + k], r2 = r * r;
+#if MVRL_F64
+        // fp64: Taylor to r^11 / r^12 - truncation 2.4e-18 / 4e-20 at |r| = 0.25, below the rounding of the result
+        const float ps = fmaf(fmaf(fmaf(fmaf(-2.5052108385441720e-8f, r2, 2.7557319223985893e-6f), r2, -1.9841269841269841e-4f), r2, 8.3333333333333332e-3f), r2, -1.6666666666666666e-1f);
+        sd[k] = fmaf(ps * r2, r, r);
+        const float pc = fmaf(fmaf(fmaf(fmaf(2.0876756987868099e-9f, r2, -2.7557319223985888e-7f), r2, 2.4801587301587302e-5f), r2, -1.3888888888888889e-3f), r2, 4.1666666666666664e-2f);
+        cd[k] = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+#else
         const float ps = fmaf(8.333333333e-3f, r2, -1.666666667e-1f);          // sin r = r + r^3 (-1/6 + r^2 / 120)
         sd[k] = fmaf(ps * r2, r, r);
         const float pc = fmaf(-1.388888889e-3f, r2, 4.166666667e-2f);          // cos r = 1 - r^2 / 2 + r^4 (1/24 - r^2 / 720)
         cd[k] = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+#endif
     }
     t.sph = fmaf(b.cph, sd[0], b.sph * cd[0]); t.cph = fmaf(-b.sph, sd[0], b.cph * cd[0]);
     t.sth = fmaf(b.cth, sd[1], b.sth * cd[1]); t.cth = fmaf(-b.sth, sd[1], b.cth * cd[1]);
@@ -480,7 +519,7 @@ __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, con
 // rounding than a rotation from the base attitude).  A lane with a larger eps takes the general path from the base attitude.
 template <class SP>
 __device__ __forceinline__ Trig6 stage3_trig(const Trig6& t2, const Trig6& tb, const float* yt, const float* eps, const float* d2, const SP& sp) {
-#if MVRL_F64 || defined(MVRL_FULL_STAGE_TRIG) || defined(MVRL_NO_STAGE3_SMALL)
+#if defined(MVRL_FULL_STAGE_TRIG) || defined(MVRL_NO_STAGE3_SMALL)
     return stage_trig<true>(tb, yt, d2, sp);
 #else
     Trig6 t;
@@ -488,8 +527,14 @@ __device__ __forceinline__ Trig6 stage3_trig(const Trig6& t2, const Trig6& tb, c
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float r = eps[3 + k], r2 = r * r;
+#if MVRL_F64
+        // fp64: Taylor to r^7 / r^8 - truncation 5e-18 / 3e-20 at |r| = 0.05
+        sd[k] = r * fmaf(r2, fmaf(r2, fmaf(r2, -1.9841269841269841e-4f, 8.3333333333333332e-3f), -1.6666666666666666e-1f), 1.0f);
+        cd[k] = fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.4801587301587302e-5f, -1.3888888888888889e-3f), 4.1666666666666664e-2f), -0.5f), 1.0f);
+#else
         sd[k] = r * fmaf(r2, -1.666666667e-1f, 1.0f);
         cd[k] = fmaf(r2, fmaf(r2, 4.166666667e-2f, -0.5f), 1.0f);
+#endif
     }
     t.sph = fmaf(t2.cph, sd[0], t2.sph * cd[0]); t.cph = fmaf(-t2.sph, sd[0], t2.cph * cd[0]);
     t.sth = fmaf(t2.cth, sd[1], t2.sth * cd[1]); t.cth = fmaf(-t2.sth, sd[1], t2.cth * cd[1]);
@@ -670,11 +715,10 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     if (i_in >= (uint32_t)io.lane_end) return;
     const int k_steps = MULTI ? io.k_steps : 1;
 #ifdef MVRL_PARK_ON
-    __shared__ float4 park_lds[MVRL_PARK_FLOAT4S];
-    static_assert(MVRL_PARK_FLOAT4S >= 2 * 3 * MVRL_STEP_BLOCK, "parking tile");
-    const Park12 park_y{park_lds}, park_a{park_lds + 3 * MVRL_STEP_BLOCK};
-    static_assert(MVRL_PARK_FLOAT4S >= 10 * MVRL_STEP_BLOCK, "parking tile + origin store + start-of-step error");
-    SpStore sps{park_lds + 6 * MVRL_STEP_BLOCK}, e0s{park_lds + 8 * MVRL_STEP_BLOCK};
+    __shared__ park_vec park_lds[MVRL_PARK_FLOAT4S];
+    const Park12 park_y{park_lds}, park_a{park_lds + MVRL_PARK_V12 * MVRL_STEP_BLOCK};
+    static_assert(MVRL_PARK_FLOAT4S >= (2 * MVRL_PARK_V12 + 2 * MVRL_PARK_V8) * MVRL_STEP_BLOCK, "parking tiles + origin store + start-of-step error");
+    SpStore sps{park_lds + 2 * MVRL_PARK_V12 * MVRL_STEP_BLOCK}, e0s{park_lds + (2 * MVRL_PARK_V12 + MVRL_PARK_V8) * MVRL_STEP_BLOCK};
 #else
     SpStore sps, e0s;
 #endif
@@ -737,8 +781,12 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     const bool first = (istep == 0);  // controller.eOld is None until the first call (6DoF.py:62-63)
     istep += 1;                       // 6DoF.py:533
     FlowTap tap;
-    if (FLOW)  // sampled once per env step at the pre-step position, time AFTER the increment
-        tap = flow_gather(fl, (float)istep * io.dt + toff, y[0], y[1]);
+    if (FLOW) {  // sampled once per env step at the pre-step position, time AFTER the increment; the time in fp64
+        int kk;
+        float ft;
+        flow_time_index(fl, istep, io.dt64, toff, kk, ft);
+        tap = flow_gather(fl, kk, ft, y[0], y[1]);
+    }
     // ERROR COORDINATES.  The set-point is constant inside an env step and the pose enters the right-hand side only through
     // the controller's error e = setPoint - pose (and through sines and cosines, which are carried by rotation, stage_trig).
     // The RK4 loop below therefore integrates z = setPoint - pose instead of the pose: dz/dt = -J nu.  In the reference's

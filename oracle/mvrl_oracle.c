@@ -268,6 +268,16 @@ static double noise_u(uint64_t* st) {   /* splitmix64 -> U(-1, 1) */
     z ^= z >> 31;
     return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
 }
+/* Rounding emulation (tests/audit/attribution_cpu.py only; off for every golden-vector check): switches that make the fp64 build
+ * commit ONE class of fp32 rounding, so that its effect on a whole episode can be measured alone.
+ *   1: every RHS output (dy) rounded to fp32 - the least any fp32 right-hand side commits (one rounding of each result)
+ *   2: the turbulence sample time formed in fp32, as the round-4 kernels did (flow_gather of that round)
+ *   4: the sampled current (u_c, v_c) rounded to fp32
+ *   8: the state rounded to fp32 after every RK4 sub-step (instead of once per env step, which the callers do on the arrays) */
+static int FN(g_emulate) = 0;
+void FN(orc_set_emulate)(int mask) { FN(g_emulate) = mask; }
+static inline real emu_round(real x) { return (real)(float)x; }
+
 static const real* noisy_rpm(const real* rpm, int n, real* buf) {
     if (!(FN(tl_noise) > 0)) return rpm;
     for (int k = 0; k < n; k++) buf[k] = rpm[k] * (real)(1.0 + FN(tl_noise) * noise_u(&FN(tl_rng)));
@@ -437,6 +447,8 @@ static void rhs_eval(rhs_ctx* c, double t, const real* y, real* dy) {
         if (c->zoh) rhs3_given_rpm(c->p3, y, c->rpm, c->cur, dy);
         else FN(orc_derivs3)(c->p3, t, y, c->sp, c->pid, c->cur, dy, c->gcf, c->rpm);
     }
+    if (FN(g_emulate) & 1)
+        for (int i = 0; i < 2 * c->dof; i++) dy[i] = emu_round(dy[i]);
 }
 
 static void zoh_control(rhs_ctx* c, double t, const real* y) {
@@ -471,6 +483,8 @@ static void integrate_rk4(rhs_ctx* c, double t0, double dt, int n_sub, real* y) 
         for (int i = 0; i < n; i++) y[i] = y[i] + (hh / 6) * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
         if (FN(tl_noise) > 0)
             for (int i = 0; i < n; i++) y[i] *= (real)(1.0 + FN(tl_noise) * noise_u(&FN(tl_rng)));
+        if (FN(g_emulate) & 8)
+            for (int i = 0; i < n; i++) y[i] = emu_round(y[i]);
     }
 }
 
@@ -701,8 +715,12 @@ int FN(orc_rov_step)(int dof, const mvrl_rov6_params* p6, const mvrl_rov3_params
         real cur[2] = {0, 0};
         if (flow_table) { /* sampled once per step at the pre-step position, as verySimpleAuv.py:291 */
             real res[2];
-            FN(orc_flow_sample_bounded)(flow_table, f_nt, f_ny, f_nx, 2, f_dt, f_dx, f_dy, (real)time[e] + toffset[e], ye[0], ye[1], res);
+            real tsample = (real)time[e] + toffset[e];
+            if (FN(g_emulate) & 2)   /* the round-4 kernels: ((float)istep * dt + toff) * (1 / dt_table), all in fp32 */
+                tsample = (real)(((float)istep[e] * (float)dt + (float)toffset[e]) * (float)(1.0 / f_dt)) * (real)f_dt;
+            FN(orc_flow_sample_bounded)(flow_table, f_nt, f_ny, f_nx, 2, f_dt, f_dx, f_dy, tsample, ye[0], ye[1], res);
             cur[0] = res[0]; cur[1] = res[1];
+            if (FN(g_emulate) & 4) { cur[0] = emu_round(cur[0]); cur[1] = emu_round(cur[1]); }
         }
         rhs_ctx c;
         memset(&c, 0, sizeof(c));

@@ -151,3 +151,40 @@ def test_precision_entry_points_are_checked():
     with pytest.raises(_lib.MvrlError, match="F64"):
         _lib.Handle(P.make_config("rov6", 4, use_flow=False, integrator="rk45"))    # RK45 needs fp64
     h32.close(); h64.close()
+
+
+@pytest.mark.parametrize("which", ["c4", "c3", "c2"])
+def test_f64_whole_episode_follows_the_reference(oracle_mod, which):
+    """The mode that follows the reference for a WHOLE 250-step episode (6DoF.py:569-571) on the benched populations (VERDICT r4
+    "next 1"): precision = f64, 4096 envs, Philox resets, uniform random actions.  Under random actions the closed loop is chaotic
+    (every fp32 build loses 40 % of the C4 envs by step 250, tests/audit/attribution_cpu.py says why); in fp64 NO env may leave 1e-5
+    and the worst one stays below 1e-6."""
+    from marinevehiclereinforcementlearning_amd.flow import ReconstructedFlow
+    n, steps = 4096, 250
+    dof = 3 if which == "c2" else 6
+    npos = 3 if dof == 6 else 2
+    h = _lib.Handle(P.make_config("rov6" if dof == 6 else "rov3", n, auto_reset=False, max_steps=10 ** 9, use_flow=which == "c4",
+                                  seed=12345, precision="f64"))
+    ft = None
+    if which == "c4":
+        flow = ReconstructedFlow.synthetic(n_modes=8, n_time=2000)
+        flow.scale(11., 1., 2., translate=(-1.65, -1.1))
+        uv = flow.table_uv()
+        h.set_flow(uv, flow.dt, flow.dx, flow.dy)
+        ft = oracle_mod.FlowTable(uv.astype(np.float64), flow.dt, flow.dx, flow.dy)
+    h.reset()
+    st = h.get_state()
+    init = np.concatenate([st[5 * dof:5 * dof + 2 * npos].T, st[4 * dof:5 * dof].T[:, npos:]], axis=1)
+    ref = oracle_mod.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft)
+    ref.reset(init, toffset=st[-2].copy())
+    ang = [3, 4, 5] if dof == 6 else [2]
+    rng = np.random.default_rng(2024)
+    worst = np.zeros(n)
+    for s in range(steps):
+        a = rng.uniform(-1, 1, (n, dof)).astype(np.float32).astype(np.float64)
+        ref.step(a)
+        h.step(a)
+        worst = np.maximum(worst, circ_err(h.get_state()[:2 * dof].T, ref.y, ang).max(axis=1))
+    print(f"f64 {which}: worst env {worst.max():.1e}, median {np.median(worst):.1e}, beyond 1e-5: {int((worst > 1e-5).sum())} of {n} after {steps} steps")
+    assert (worst > 1e-5).sum() == 0 and worst.max() < 1e-6, worst.max()
+    h.close()

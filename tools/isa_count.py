@@ -16,23 +16,24 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "marinevehiclereinforcementlearning_amd", "csrc")
 
 
-def compile_s(extra, out):
+def compile_s(extra, out, f64=False):
     sys.path.insert(0, REPO)
     from marinevehiclereinforcementlearning_amd import build
     build._gen_baked()
-    flags = [f for f in build.FLAGS if f not in ("-fPIC",)]
-    cmd = ["/opt/rocm/bin/hipcc"] + flags + list(extra) + ["-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "mvrl_rov6.hip")]
+    flags = [f for f in (build.flags_for("gen/mvrl_rov6_f64.hip") if f64 else build.FLAGS) if f not in ("-fPIC",)]
+    src = os.path.join(CSRC, "gen", "mvrl_rov6_f64.hip") if f64 else os.path.join(CSRC, "mvrl_rov6.hip")
+    cmd = ["/opt/rocm/bin/hipcc"] + flags + list(extra) + ["-S", "--cuda-device-only", "-o", out, src]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 
 
-def analyse(path, sym):
+def analyse(path, sym, loop_depth=2):
     L = open(path).read().split("\n")
     start = next(i for i, l in enumerate(L) if l.startswith(sym + ":"))
     end = next(i for i in range(start, len(L)) if L[i].startswith(".Lfunc_end"))
     body = L[start:end]
     info = {}
     for l in L[end:end + 200]:
-        m = re.match(r"\s*\.set .*\.(num_vgpr|numbered_sgpr|private_seg_size), (\d+)", l)
+        m = re.match(r"\s*\.set .*\.(num_vgpr|num_agpr|numbered_sgpr|private_seg_size), (\d+)", l)
         if m:
             info.setdefault(m.group(1), int(m.group(2)))
     # walk the body: loop depth from the block labels' comments; lines behind `s_and_saveexec` + `s_cbranch_execz L` up to label L
@@ -53,10 +54,10 @@ def analyse(path, sym):
         mb = re.match(r"s_cbranch_execz (\.LBB\d+_\d+)", st)
         if mb and "saveexec" in prev and skip_to is None and seen_label:      # (the first one is the lane-range guard of the whole kernel)
             skip_to = mb.group(1)
-            if depth >= 2:
+            if depth >= loop_depth:
                 slow.append(0)
         is_valu = bool(re.match(r"^\s+v_", l))
-        if depth >= 2:
+        if depth >= loop_depth:
             if skip_to is not None:
                 slow[-1] += is_valu
             else:
@@ -78,13 +79,15 @@ if __name__ == "__main__":
     zoh = "--zoh" in args
     flow = "--noflow" not in args
     fixed = "--fixed" in args
-    extra = [a for a in args if a.startswith("-D") or a.startswith("-m")]
-    out = "/tmp/isa/count.s"
+    f64 = "--f64" in args      # the fp64 twin (csrc/gen/mvrl_rov6_f64.hip, its own flags; single-step instance)
+    extra = [a for a in args if a.startswith("-D") or a.startswith("-m") or a.startswith("-f")]
+    out = "/tmp/isa/count64.s" if f64 else "/tmp/isa/count.s"
     os.makedirs("/tmp/isa", exist_ok=True)
-    compile_s(extra, out)
+    compile_s(extra, out, f64)
     b = lambda v: "Lb1E" if v else "Lb0E"
-    sym = "_ZN4mvrl16rov6_step_kernelIPKNS_9Rov6BakedELb1E" + b(zoh) + b(flow) + "Li0ELb1E" + b(fixed) + "EEvPKNS_7Rov6DevENS_6StepIOENS_7FlowDevE"
-    r = analyse(out, sym)
+    ns = "_ZN6mvrl6416" if f64 else "_ZN4mvrl16"
+    sym = ns + "rov6_step_kernelIPKNS_9Rov6BakedELb1E" + b(zoh) + b(flow) + "Li0E" + b(not f64) + b(fixed) + "EEvPKNS_7Rov6DevENS_6StepIOENS_7FlowDevE"
+    r = analyse(out, sym, 1 if f64 else 2)   # the fp64 single-step instance has no fused-launch loop around the sub-step loop
     est = 4 * r["fast"] + r["outer"]
     print(f"sub-step loop: fast path {r['fast']} VALU, divergent blocks {r['slow']}, {r['lds']} LDS; outside the loop {r['outer']} (+{r['outer_divergent']} divergent: reset); "
-          f"4 x fast + outside = {est}; vgpr {r.get('num_vgpr')} sgpr {r.get('numbered_sgpr')} scratch {r.get('private_seg_size')}")
+          f"4 x fast + outside = {est}; vgpr {r.get('num_vgpr')} agpr {r.get('num_agpr')} sgpr {r.get('numbered_sgpr')} scratch {r.get('private_seg_size')}")

@@ -11,6 +11,13 @@ sys.path.insert(0, REPO)
 OUT = os.path.join(REPO, "variants_build")  # *.so is git-ignored; gpurun_out/ does not travel to the GPU box
 VARIANTS = {
     "base": dict(extra=[], drop=()),
+    # the fp64 twins (the exactness path) under other floating-point models: IEEE without contraction (rounds 1-4), full fast-math
+    "f64strict": dict(extra=[], drop=(), f64=["-ffp-contract=off"]),
+    "f64fast": dict(extra=[], drop=(), f64=["-ffast-math"]),
+    "f64nopark": dict(extra=["-DMVRL_NO_PARK"], drop=()),
+    "f64fulltrig": dict(extra=["-DMVRL_FULL_STAGE_TRIG"], drop=()),
+    # attribution (tests/audit/episode_audit.py): the round-4 fp32 turbulence sample time
+    "flowt32": dict(extra=["-DMVRL_FLOW_TIME_F32"], drop=()),
     # profiling build: per-wave s_memtime stamps at the phase boundaries of the 6-DoF step kernel (tools/stamp_probe.py)
     "stamp": dict(extra=["-DMVRL_STAMP"], drop=()),
     # ablations of choices the default build makes
@@ -53,8 +60,8 @@ def build_all(names):
 
     def one(name):
         v = VARIANTS[name]
-        return build.build_lib(extra_flags=v["extra"], out=os.path.join(OUT, f"libmvrl_{name}.so"), drop_flags=v["drop"])
-    with ThreadPoolExecutor(max_workers=4) as ex:
+        return build.build_lib(extra_flags=v["extra"], out=os.path.join(OUT, f"libmvrl_{name}.so"), drop_flags=v["drop"], f64_flags=v.get("f64"))
+    with ThreadPoolExecutor(max_workers=2) as ex:   # each build compiles its sources four at a time
         print(list(ex.map(one, names)))
 
 
