@@ -39,6 +39,12 @@ sys.path.insert(0, REPO)
 # algorithmic bytes per env step (stated again in DESIGN.md)
 WORKLOADS = {
     "c4": dict(model="rov6", n=1048576, flow=True, bytes=365, io=129, name="6-DoF + turbulence, 1 048 576 envs per GPU (BASELINE configs[3]; x8 = configs[4])"),
+    # the same kernel family with the vehicles HELD INSIDE the 3.3 m x 2.2 m table (fixed set-points drawn inside it, 6DoF.py:536-541;
+    # random time offsets): every lookup is a real scattered cell of the 80 MB the offsets span, where c4's random-action vehicles
+    # drift out of the table within seconds and mostly re-read its clamped edge (VERDICT r4 "weak 7").  341 B: the fixed-set-point
+    # flavour reads the set-point planes instead of an action row and does not write them back
+    "c4in": dict(model="rov6", n=1048576, flow=True, bytes=341, io=105, in_table=True,
+                 name="6-DoF + turbulence, fixed set-points INSIDE the table, 1 048 576 envs (table-resident variant of configs[3])"),
     "c3": dict(model="rov6", n=262144, flow=False, bytes=297, io=65, name="6-DoF, 262 144 envs (BASELINE configs[2])"),
     "c2": dict(model="rov3", n=65536, flow=False, bytes=165, io=37, name="3-DoF, 65 536 envs (BASELINE configs[1])"),
     "auv": dict(model="auv", n=1048576, flow=True, bytes=389, io=125, name="AuvEnv + turbulence, 1 048 576 envs"),
@@ -89,15 +95,17 @@ def cpu_baseline(wl, flow_np, seed):
         env.reset(init, toffset=rng.random(n) * 5.0 if ft is not None else None)
         act = rng.uniform(-1, 1, size=(n, dof))
     env.step(act)                      # first touch: thread start-up, page faults
+    # TIME-BOXED: steps until CPU_BASELINE_S seconds have elapsed (a step count planned from two warm steps once ran 68 s instead of
+    # 15: the later steps of an episode are several times slower than the first ones - VERDICT r4 "weak 8")
+    budget = float(os.environ.get("MVRL_CPU_BASELINE_S", "12"))
+    steps = 0
     t0 = time.perf_counter()
-    for _ in range(2):
+    while True:
         env.step(act)
-    one = (time.perf_counter() - t0) / 2
-    steps = int(max(3, min(2000, 10.0 / max(one, 1e-4))))     # 10-20 s of CPU work (later steps run slower than the first warm ones)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        env.step(act)
-    el = time.perf_counter() - t0
+        steps += 1
+        el = time.perf_counter() - t0
+        if (el >= budget and steps >= 3) or steps >= 5000:
+            break
     # the reference itself cannot travel to the GPU box; its own NumPy figures, measured in the build container, ride along
     ref_np = {"rov6": {"value": 21.7, "under_rk4_harness": 250.0,
                        "what": "BlueROV2Heavy6DoFEnv.step, random actions, 300 steps (adaptive RK45, 181 derivs per step); "
@@ -252,7 +260,7 @@ def main():
               "generic": lambda: P_.rov6_params(CG=[0.01, -0.015, 0.04], Yr=-0.3, m=12.0)}[args.flavour]()
     env = MarineVecEnv(wl["model"], n, seed=args.seed, n_substeps=args.n_substeps, control_mode=args.control_mode,
                        flow=flow, device=local_rank, env_offset=rank * n, infos="lean", precision=args.precision,
-                       vehicle_params=vp, specialize=bool(args.specialize and (vp is not None or os.environ.get("MVRL_JIT_FORCE"))))
+                       fixed_setpoint=bool(wl.get("in_table")), vehicle_params=vp, specialize=bool(args.specialize and (vp is not None or os.environ.get("MVRL_JIT_FORCE"))))
     act_dim, obs_dim = env.action_space.shape[0], env.observation_space.shape[0]
     h = env.handle
     stream = torch.cuda.current_stream().cuda_stream
@@ -263,6 +271,16 @@ def main():
         ring = ring.double()
         wl["bytes"] *= 2  # every word of state / action / observation is 8 bytes wide
     env.reset_tensors()
+    if wl.get("in_table"):
+        # fixed set-points inside the table (x in [0.4, 2.9] m, y in [0.4, 1.8] m: interp ignores the origin, flowGenerator.py:118-120),
+        # depth +-1 m, roll / pitch targets within +-0.2 rad, any yaw; time offsets as a random reset draws them (verySimpleAuv.py:245)
+        rng = np.random.default_rng(args.seed + 7919 * rank)
+        spx = np.stack([rng.uniform(0.4, 2.9, n), rng.uniform(0.4, 1.8, n), rng.uniform(-1.0, 1.0, n)], axis=1)
+        ang = np.stack([rng.uniform(-0.2, 0.2, n) % (2 * np.pi), rng.uniform(-0.2, 0.2, n) % (2 * np.pi), rng.uniform(0, 2 * np.pi, n)], axis=1)
+        env.reset(init=np.concatenate([spx, spx, ang], axis=1))
+        st = h.get_state(raw=True)
+        st[-2] = (rng.random(n) * (2000 // 4) * flow.dt).astype(st.dtype)      # plane R6_TOFF (include/mvrl.h)
+        h.set_state(st, raw=True)
 
     def sync():
         torch.cuda.synchronize()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MVRL_ABI_VERSION 3
+#define MVRL_ABI_VERSION 4
 
 /* ---- models (which reference environment the handle replaces) ------------------------------ */
 #define MVRL_MODEL_AUV 0  /* AuvEnv, explicit Euler + turbulence current   tag/verySimpleAuv.py:76-416 */
@@ -247,14 +247,16 @@ int mvrl_step_dev(mvrl_handle* h, const void* actions_dev, void* obs_dev, void* 
 int mvrl_step_range_dev(mvrl_handle* h, int64_t first_env, int64_t n_range, const void* actions_dev, void* obs_dev,
                         void* reward_dev, uint8_t* done_dev, void* stream);
 
+/* The handle's own pinned, device-visible staging block of the host-buffer step: actions[n_envs, act_dim], obs[n_envs, obs_dim],
+ * reward[n_envs] in the handle's precision, done[n_envs] u8 - valid for the handle's lifetime (freed by mvrl_destroy).  A caller that
+ * writes its actions THERE and passes these very pointers to mvrl_step / mvrl_step_async / mvrl_step_wait saves the two staging
+ * copies of a step (SB3's numpy buffers are ordinary pageable memory, which is why the copies exist: 25 + 43 MB per step at
+ * 1 048 576 6-DoF envs); outputs are overwritten by the next step.  The ACTION block must not be written between mvrl_step_async
+ * and the matching mvrl_step_wait: for small batches (n_envs <= 4096) the kernel in flight reads it directly (any OTHER caller
+ * buffer handed to mvrl_step_async is free again when the call returns). */
+int mvrl_host_buffers(mvrl_handle* h, void** actions, void** obs, void** reward, uint8_t** done);
 /* Observation of the step on which an env finished (SB3 infos[i]["terminal_observation"]); rows of envs
  * that did not finish on the last step are unspecified.  Only meaningful with auto_reset = 1. */
-/* The handle's own pinned, device-visible staging block of the host-buffer step: actions[n_envs, act_dim], obs[n_envs, obs_dim],
- * reward[n_envs] in the handle's precision, done[n_envs] u8 - valid for the handle's lifetime.  A caller that writes its actions
- * THERE and passes these very pointers to mvrl_step / mvrl_step_async / mvrl_step_wait saves the two staging copies of a step (SB3's
- * numpy buffers are ordinary pageable memory, which is why the copies exist: 25 + 43 MB per step at 1 048 576 6-DoF envs); outputs are
- * overwritten by the next step. */
-int mvrl_host_buffers(mvrl_handle* h, void** actions, void** obs, void** reward, uint8_t** done);
 int mvrl_get_terminal_obs(mvrl_handle* h, float* obs);
 int mvrl_get_terminal_obs_f64(mvrl_handle* h, double* obs);
 /* k_steps consecutive env steps in one call: actions_dev [k][n][act_dim], obs_dev [k][n][obs_dim], reward_dev [k][n],
@@ -306,6 +308,59 @@ int mvrl_derivs(mvrl_handle* h, int64_t n, const double* t, const float* y, cons
                 const uint8_t* has_old, float* dy, float* gcf, float* rpm);
 int mvrl_derivs_f64(mvrl_handle* h, int64_t n, const double* t, const double* y, const double* sp, double* eold, double* eint,
                     double* told, const uint8_t* has_old, double* dy, double* gcf, double* rpm);
+/* The same call with a water current: cur[n,2] = (u_c, v_c) in the GLOBAL frame per tuple (NULL = zero = mvrl_derivs) - the
+ * `velCurrent` the reference declares and leaves at zero ("TODO add a current model", 3DoF.py:182-191, 6DoF.py:257-267): resolved
+ * into the body frame (3-DoF: pinv(J) = J^T; 6-DoF: globalToVehicle of the translational part), velRel = vel - velCurrent enters
+ * Ca / Dq (3-DoF) and the (Ca + D) velRel product (both).  What the step kernels apply when a turbulence table is set
+ * (SURVEY 9.5); pinned by goldens G21 / G22, which EXECUTE those reference lines with a non-zero current (ABI 4). */
+int mvrl_derivs_cur(mvrl_handle* h, int64_t n, const double* t, const float* y, const float* sp, const float* cur, float* eold,
+                    float* eint, double* told, const uint8_t* has_old, float* dy, float* gcf, float* rpm);
+int mvrl_derivs_cur_f64(mvrl_handle* h, int64_t n, const double* t, const double* y, const double* sp, const double* cur, double* eold,
+                        double* eint, double* told, const uint8_t* has_old, double* dy, double* gcf, double* rpm);
+
+/* ---- groups: the GPUs of one node behind ONE object in ONE host process (ABI 4) ---------------------------------------------
+ * Replaces SB3's SubprocVecEnv - one Python process per env, pipe send / recv around env.step (tag/main_00_sbl.py:145-146) - for a
+ * caller without torch.distributed (BASELINE configs[4] from C).  The batch of cfg->n_envs environments is cut into contiguous
+ * shards (mvrl_group_shard_range: the first n_envs % n_devices shards own one env more); shard i is an ordinary handle on
+ * devices[i] with env_offset = cfg->env_offset + its first env, so random resets - Philox keyed by the GLOBAL env id - make the
+ * shards together bit-identical to the unsharded batch.  A step is one launch per device with no host synchronisation between
+ * them; the ONE exchange of the path, returning (observation, reward, done) to the root device, is a grouped ncclSend / ncclRecv
+ * over RCCL / xGMI (librccl is dlopen-ed at group creation: the library itself loads without it).  A group of one device, one with
+ * a repeated device (RCCL refuses duplicates: rehearsal on a 1-GPU box) or MVRL_GROUP_TRANSPORT=copy moves the messages with
+ * device-to-device / peer copies instead.  fp32 handles only (the message is an fp32 format).  Not re-entrant: one host thread
+ * at a time per group.
+ * Message per shard (the step kernel writes its outputs straight into it; = distributed.OutputGather's format):
+ *   obs[cmax, obs_dim] f32 | reward[cmax] f32 (AuvEnv only: the rigid-body reward is identically 0, 6DoF.py:575) | done[cmax] u8,
+ *   padded to 16 B; cmax = the largest shard.  The root holds [n_shards][msg_bytes], twice (gather k overlaps step k + 1). */
+typedef struct mvrl_group mvrl_group;
+typedef struct mvrl_group_layout {
+    int64_t n_global;
+    int32_t n_shards, obs_dim, reward_plane;
+    int32_t transport;      /* 0: device-to-device / peer copies, 1: RCCL (filled by mvrl_group_info) */
+    int64_t cmax, off_reward, off_done, msg_bytes;
+} mvrl_group_layout;
+int mvrl_group_shard_range(int64_t n_global, int32_t shard, int32_t n_shards, int64_t* first, int64_t* count);   /* no GPU needed */
+int mvrl_group_message_layout(int64_t n_global, int32_t n_shards, int32_t obs_dim, int32_t reward_plane, mvrl_group_layout* out); /* no GPU needed */
+/* cfg: as for mvrl_create with n_envs = the GLOBAL env count (cfg->device is ignored); root = index INTO devices[] of the gather's target */
+int mvrl_group_create(const mvrl_config* cfg, const int32_t* devices, int32_t n_devices, int32_t root, mvrl_group** out);
+void mvrl_group_destroy(mvrl_group* g);
+const char* mvrl_group_last_error(const mvrl_group* g);
+int mvrl_group_info(const mvrl_group* g, mvrl_group_layout* out);
+mvrl_handle* mvrl_group_shard(mvrl_group* g, int32_t shard);            /* the shard's handle: mvrl_get_state, mvrl_reset with explicit values ... */
+int mvrl_group_set_flow(mvrl_group* g, const float* table_host, const mvrl_flow_desc* desc);   /* replicated on every device */
+int mvrl_group_reset(mvrl_group* g);                                     /* random resets everywhere; first observations into the current message */
+/* actions_dev[i]: pointer ON DEVICE i to shard i's rows [count_i, act_dim] f32; NULL (array or entry) = the group's own action
+ * buffer of that shard (mvrl_group_scatter_actions_dev / mvrl_group_fill_actions); nothing is read with a fixed set-point */
+int mvrl_group_step_dev(mvrl_group* g, const void* const* actions_dev);
+int mvrl_group_gather_dev(mvrl_group* g);                               /* the last step's (or reset's) messages -> root; asynchronous */
+int mvrl_group_wait(mvrl_group* g);                                     /* host blocks until the last gather has arrived */
+int mvrl_group_gathered_event(mvrl_group* g, void** hip_event);         /* ... or order a consumer stream behind it: hipStreamWaitEvent */
+/* root-device pointers to one shard's rows of the last gather (reward NULL for the rigid-body models); first / count: its global range */
+int mvrl_group_root_views(mvrl_group* g, int32_t shard, const float** obs, const float** reward, const uint8_t** done, int64_t* first, int64_t* count);
+int mvrl_group_download(mvrl_group* g, float* obs, float* reward, uint8_t* done);   /* last gather to host arrays in global env order */
+int mvrl_group_scatter_actions_dev(mvrl_group* g, const float* actions_root_dev);   /* [n_global, act_dim] on the root device -> the shards */
+int mvrl_group_fill_actions(mvrl_group* g, uint64_t seed, uint64_t counter, float lo, float hi);   /* synthetic roll-outs: uniform actions per shard */
+int mvrl_group_synchronize(mvrl_group* g);
 
 /* ---- run-time specialisation (6-DoF, fp32, RK4 harness).  libmvrl.so carries its fastest step kernel - model constants
  * as instruction literals - for the reference's default vehicle only (6DoF.py:83-218); a vehicle with other constants

@@ -28,8 +28,13 @@ SYMBOLS = [
     "mvrl_dev_upload", "mvrl_dev_download", "mvrl_synchronize",
     # fp64 twins of the host-buffer entry points + RK45 diagnostics
     "mvrl_set_flow_f64", "mvrl_reset_f64", "mvrl_step_f64", "mvrl_get_terminal_obs_f64", "mvrl_get_state_f64",
-    "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64", "mvrl_vehicle_ops", "mvrl_vehicle_ops_f64", "mvrl_specialize", "mvrl_jit_compile_check",
+    "mvrl_set_state_f64", "mvrl_get_aux_f64", "mvrl_get_nfev", "mvrl_derivs", "mvrl_derivs_f64", "mvrl_derivs_cur", "mvrl_derivs_cur_f64", "mvrl_vehicle_ops", "mvrl_vehicle_ops_f64", "mvrl_specialize", "mvrl_jit_compile_check",
     "mvrl_jit_info", "mvrl_jit_compile_check2", "mvrl_jit_child_env", "mvrl_force_components", "mvrl_force_components_f64", "mvrl_mass_solve", "mvrl_mass_solve_f64", "mvrl_observe", "mvrl_observe_f64", "mvrl_host_buffers", "mvrl_default_config",
+    # several devices behind one object in one process (csrc/mvrl_group.hip; Python: group.DeviceGroup)
+    "mvrl_group_shard_range", "mvrl_group_message_layout", "mvrl_group_create", "mvrl_group_destroy", "mvrl_group_last_error", "mvrl_group_info",
+    "mvrl_group_shard", "mvrl_group_set_flow", "mvrl_group_reset", "mvrl_group_step_dev", "mvrl_group_gather_dev", "mvrl_group_wait",
+    "mvrl_group_gathered_event", "mvrl_group_root_views", "mvrl_group_download", "mvrl_group_scatter_actions_dev", "mvrl_group_fill_actions",
+    "mvrl_group_synchronize",
     "mvrl_auv_pd_episodes_dev", "mvrl_rollout_dev", "mvrl_replay_add_sym_dev", "mvrl_policy_create", "mvrl_policy_destroy", "mvrl_policy_reset", "mvrl_policy_predict", "mvrl_policy_predict_dev",
 ]
 
@@ -105,6 +110,8 @@ def load(path=None):
     lib.mvrl_get_nfev.argtypes = [vp, vp]
     lib.mvrl_derivs.argtypes = [vp, i64] + [vp] * 10
     lib.mvrl_derivs_f64.argtypes = [vp, i64] + [vp] * 10
+    lib.mvrl_derivs_cur.argtypes = [vp, i64] + [vp] * 11
+    lib.mvrl_derivs_cur_f64.argtypes = [vp, i64] + [vp] * 11
     lib.mvrl_vehicle_ops.argtypes = [vp, i64] + [vp] * 8
     lib.mvrl_specialize.argtypes = [vp]
     lib.mvrl_jit_compile_check.argtypes = [vp, C.c_int, vp, vp, C.c_size_t]
@@ -229,14 +236,15 @@ class Handle:
         check(self.lib.mvrl_set_flow_dev(self.h, ptr, C.byref(d)), self.h)
 
     # -- host-buffer API --------------------------------------------------------------------------
-    def reset(self, mask=None, init=None, obs_out=None):
+    def reset(self, mask=None, init=None, obs_out=None, copy=True):
+        """copy=False hands out the handle's pinned staging block itself (see `step`); a caller-supplied obs_out is returned as it is."""
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.n)
         ini = None if init is None else _real(init, self.dtype, (self.n, self.init_dim))
         obs = self._obs if obs_out is None else obs_out
         assert obs.dtype == self.dtype
         check(self._fn("mvrl_reset")(self.h, None if m is None else m.ctypes.data,
                                      None if ini is None else ini.ctypes.data, obs.ctypes.data), self.h)
-        return obs
+        return obs.copy() if (copy and obs_out is None) else obs
 
     def _stage_actions(self, actions):
         """actions -> the handle's pinned action block (one copy, with dtype conversion if needed); returns its address or None"""
@@ -245,21 +253,33 @@ class Handle:
         np.copyto(self._act_in, np.asarray(actions).reshape(self.n, self.act_dim), casting="same_kind")
         return self._act_in.ctypes.data
 
-    def step(self, actions):
-        """One env step through host buffers.  The returned arrays are views of the handle's pinned staging block: valid until the next
-        step (MarineVecEnv hands out copies)."""
+    def step(self, actions, copy=True):
+        """One env step through host buffers: (obs [n, obs_dim], reward [n], done bits [n]) as FRESH arrays, like the reference's step
+        (SURVEY 8(b) "Ownership").  copy=False: zero-copy VIEWS of the handle's pinned staging block (mvrl_host_buffers) - overwritten
+        by the next step / reset and INVALID once the handle is closed or collected (the block is freed with it); for callers that
+        consume the outputs at once (MarineVecEnv, which hands out its own copies; the PCIe-inclusive benchmarks)."""
         check(self._fn("mvrl_step")(self.h, self._stage_actions(actions), self._obs.ctypes.data,
                                     self._rew.ctypes.data, self._done.ctypes.data), self.h)
+        if copy:
+            return self._obs.copy(), self._rew.copy(), self._done.copy()
         return self._obs, self._rew, self._done
 
     def step_async(self, actions):
         if self.f64:
             raise MvrlError("step_async/step_wait are fp32-only; fp64 handles use step()")
+        if getattr(self, "_async_pending", False):
+            # refused BEFORE the actions are staged: for small batches the in-flight kernel reads the pinned action block directly, and
+            # staging a second batch over it would change the pending step's actions (the C side would only then answer MVRL_ESTATE)
+            raise MvrlError("step_async: a step is already pending (call step_wait first)")
         check(self.lib.mvrl_step_async(self.h, self._stage_actions(actions)), self.h)
+        self._async_pending = True
 
-    def step_wait(self):
+    def step_wait(self, copy=True):
         check(self.lib.mvrl_step_wait(self.h, self._obs.ctypes.data, self._rew.ctypes.data, self._done.ctypes.data),
               self.h)
+        self._async_pending = False
+        if copy:
+            return self._obs.copy(), self._rew.copy(), self._done.copy()
         return self._obs, self._rew, self._done
 
     def terminal_obs(self):
@@ -311,9 +331,9 @@ class Handle:
         st = self.get_state() if state is None else state
         return st[P.STATE_PLANES[self.model]["episode"]].view(self.itype)
 
-    def derivs(self, t, y, sp, eold=None, eint=None, told=None, has_old=None):
+    def derivs(self, t, y, sp, eold=None, eint=None, told=None, has_old=None, cur=None):
         """vehicle.derivs(t, y) for n tuples (6DoF.py:406-442 / 3DoF.py:128-296).  Returns dict(dy, eold, eint, told, gcf,
-        rpm) - eold/eint/told are the controller memory AFTER the call."""
+        rpm) - eold/eint/told are the controller memory AFTER the call.  cur [n, 2]: a global-frame water current per tuple."""
         dof = 6 if self.model == P.MODEL_ROV6 else 3
         nthr = 8 if dof == 6 else 4
         y = np.ascontiguousarray(np.atleast_2d(y), self.dtype)
@@ -327,8 +347,14 @@ class Handle:
               np.ones(n, np.uint8) if has_old is None else np.ascontiguousarray(np.broadcast_to(has_old, (n,)), np.uint8))
         assert y.shape == (n, 2 * dof) and sp.shape == (n, dof) and eo.shape == (n, dof) and ei.shape == (n, dof)
         dy = np.zeros((n, 2 * dof), self.dtype); gcf = np.zeros((n, dof), self.dtype); rpm = np.zeros((n, nthr), self.dtype)
-        check(self._fn("mvrl_derivs")(self.h, n, t.ctypes.data, y.ctypes.data, sp.ctypes.data, eo.ctypes.data, ei.ctypes.data,
-                                      to.ctypes.data, ho.ctypes.data, dy.ctypes.data, gcf.ctypes.data, rpm.ctypes.data), self.h)
+        if cur is None:
+            check(self._fn("mvrl_derivs")(self.h, n, t.ctypes.data, y.ctypes.data, sp.ctypes.data, eo.ctypes.data, ei.ctypes.data,
+                                          to.ctypes.data, ho.ctypes.data, dy.ctypes.data, gcf.ctypes.data, rpm.ctypes.data), self.h)
+        else:   # water current (u_c, v_c) in the global frame per tuple: the reference's velCurrent hook (mvrl_derivs_cur)
+            cu = _real(np.atleast_2d(cur), self.dtype, (n, 2))
+            check(self._fn("mvrl_derivs_cur")(self.h, n, t.ctypes.data, y.ctypes.data, sp.ctypes.data, cu.ctypes.data, eo.ctypes.data,
+                                              ei.ctypes.data, to.ctypes.data, ho.ctypes.data, dy.ctypes.data, gcf.ctypes.data,
+                                              rpm.ctypes.data), self.h)
         return dict(dy=dy, eold=eo, eint=ei, told=to, gcf=gcf, rpm=rpm)
 
     def vehicle_ops(self, angles, gcf=None, rpm=None, vel=None, want=("axes", "rpm", "rhs", "thruster_h")):

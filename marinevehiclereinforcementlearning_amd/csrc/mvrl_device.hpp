@@ -157,8 +157,10 @@ __device__ __forceinline__ void bam_to_rad2(uint32_t b, float& hi, float& lo) {
 // b + (angle increment d [rad]); the wrap to [0, 2 pi) of 6DoF.py:560 is the integer overflow.  |d| of any size: reduced first.
 __device__ __forceinline__ uint32_t bam_add(uint32_t b, float d, float c_bam = MVRL_RAD_BAM) {
     d = fmaf(-rintf(d * MVRL_INV_TWO_PI), MVRL_TWO_PI_HI, d);   // |d| <= pi (1 + 1e-7): d * 2^32 / (2 pi) is within 2^31 (1 + 1e-7) ...
-    // ... where gfx950's v_cvt_i32_f32 saturates: a half turn comes out 1.5e-9 rad short at worst
-    return b + (uint32_t)(int32_t)rintf(d * c_bam);
+    // ... so the product is clamped to the largest fp32 below 2^31 before the conversion (an out-of-range float -> int conversion is
+    // undefined in C++, whatever v_cvt_i32_f32 does): an increment of exactly half a turn comes out 1.9e-7 rad short at worst
+    const float t = fminf(fmaxf(rintf(d * c_bam), -2147483520.f), 2147483520.f);
+    return b + (uint32_t)(int32_t)t;
 }
 // sin and cos of a binary angle: the top two bits (after rounding to the nearest quadrant) ARE the Cody-Waite quotient, the remainder is
 // exact, and its conversion to radians carries its rounding error along (first-order correction): ~1 ulp of the RESULT for any angle

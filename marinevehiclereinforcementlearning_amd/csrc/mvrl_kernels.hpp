@@ -7,7 +7,7 @@ namespace mvrl {
 hipError_t launch_rov6_step(const Rov6Dev* p_dev, const StepIO& io, const FlowDev& fl, bool baked, bool ctrl, bool sym, bool zoh,
                             bool flow, bool rk45, hipStream_t stream);
 hipError_t launch_rov6_derivs(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* t, const float* y, const float* sp,
-                              float* eold, float* eint, float* told, const uint8_t* has_old, float* dy, float* aux,
+                              const float* cur, float* eold, float* eint, float* told, const uint8_t* has_old, float* dy, float* aux,
                               hipStream_t stream);
 hipError_t launch_rov6_components(const Rov6Dev* p, int64_t n, const float* angles, const float* vel, const float* rpm_in, float* comp,
                                   hipStream_t stream);
@@ -18,8 +18,8 @@ hipError_t launch_rov6_unit(const Rov6Dev* p, bool baked, bool sym, int64_t n, c
 hipError_t launch_rov6_observe(const Rov6Dev* p, const float* state, int64_t n, float* obs, hipStream_t stream);
 hipError_t launch_rov3_observe(const Rov3Dev* p, const float* state, int64_t n, float* obs, hipStream_t stream);
 hipError_t launch_auv_observe(const AuvDev& p, const float* state, int64_t n, float* obs, hipStream_t stream);
-hipError_t launch_rov3_derivs(const Rov3Dev* p, bool baked, int64_t n, const float* t, const float* y, const float* sp, float* eold,
-                              float* eint, float* told, const uint8_t* has_old, float* dy, float* aux, hipStream_t stream);
+hipError_t launch_rov3_derivs(const Rov3Dev* p, bool baked, int64_t n, const float* t, const float* y, const float* sp, const float* cur,
+                              float* eold, float* eint, float* told, const uint8_t* has_old, float* dy, float* aux, hipStream_t stream);
 hipError_t launch_rov6_reset(const Rov6Dev* p_dev, float* state, int64_t n, const uint8_t* mask, const float* init, float* obs,
                              uint64_t seed, int64_t env_offset, float t_quarter, hipStream_t stream);
 

@@ -551,9 +551,9 @@ hipError_t launch_rov3_observe(const Rov3Dev* p, const float* state, int64_t n, 
 }
 
 // One evaluation of vehicle.derivs(t, y) for n independent tuples (see rov6_derivs_kernel)
-template <class PP>
+template <class PP, bool FLOW>
 __global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov3_derivs_kernel(const Rov3Dev* __restrict__ pg, int64_t n, const float* t,
-                                                                      const float* y_in, const float* sp_in, float* eold,
+                                                                      const float* y_in, const float* sp_in, const float* cur_in, float* eold,
                                                                       float* eint, float* told, const uint8_t* has_old,
                                                                       float* dy_out, float* aux_out) {
     const PP p = param_ptr<PP>(pg);
@@ -569,7 +569,9 @@ __global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov3_derivs_kernel(const Rov3
         pid.eold[0] = sp[0] - y[0]; pid.eold[1] = sp[1] - y[1]; pid.eold[2] = angle_error(sp[2], y[2]);
     }
     float to = told[i];
-    Rhs3<false, PP> rhs{p, sp, &pid, &to, make_float2(0.f, 0.f), aux_out + i * 7};
+    // cur_in (FLOW; mvrl_derivs_cur): global-frame current per tuple - the velCurrent of 3DoF.py:182-191 (golden G21)
+    const float2 cur = FLOW ? make_float2(cur_in[i * 2], cur_in[i * 2 + 1]) : make_float2(0.f, 0.f);
+    Rhs3<FLOW, PP> rhs{p, sp, &pid, &to, cur, aux_out + i * 7};
     rhs(t[i], y, dy);
 #pragma unroll
     for (int k = 0; k < 6; k++) dy_out[i * 6 + k] = dy[k];
@@ -578,11 +580,13 @@ __global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov3_derivs_kernel(const Rov3
     told[i] = to;
 }
 
-hipError_t launch_rov3_derivs(const Rov3Dev* p, bool baked, int64_t n, const float* t, const float* y, const float* sp, float* eold,
-                              float* eint, float* told, const uint8_t* has_old, float* dy, float* aux, hipStream_t stream) {
+hipError_t launch_rov3_derivs(const Rov3Dev* p, bool baked, int64_t n, const float* t, const float* y, const float* sp, const float* cur,
+                              float* eold, float* eint, float* told, const uint8_t* has_old, float* dy, float* aux, hipStream_t stream) {
     dim3 grid((unsigned)((n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
-    if (baked) hipLaunchKernelGGL((rov3_derivs_kernel<const Rov3Baked*>), grid, block, 0, stream, p, n, t, y, sp, eold, eint, told, has_old, dy, aux);
-    else hipLaunchKernelGGL((rov3_derivs_kernel<CP3>), grid, block, 0, stream, p, n, t, y, sp, eold, eint, told, has_old, dy, aux);
+#define MVRL_D3(PPT, F) hipLaunchKernelGGL((rov3_derivs_kernel<PPT, F>), grid, block, 0, stream, p, n, t, y, sp, cur, eold, eint, told, has_old, dy, aux)
+    if (cur) { if (baked) MVRL_D3(const Rov3Baked*, true); else MVRL_D3(CP3, true); }
+    else { if (baked) MVRL_D3(const Rov3Baked*, false); else MVRL_D3(CP3, false); }
+#undef MVRL_D3
     return hipGetLastError();
 }
 

@@ -1312,9 +1312,11 @@ hipError_t launch_rov6_observe(const Rov6Dev* p, const float* state, int64_t n, 
 
 // One evaluation of vehicle.derivs(t, y) for n independent (state, set-point, controller memory) tuples, row-major
 // [n, dim] arrays - the unit-level entry point (mvrl_derivs): same device functions as the step kernel.
-template <class PP, bool SYM>
+// cur_in (FLOW instances; mvrl_derivs_cur): a global-frame current (u_c, v_c) per tuple - the 6-DoF + turbulence composition's
+// velRel = vel - velCurrent branch of forceModel (6DoF.py:258-267), golden G22.
+template <class PP, bool SYM, bool FLOW>
 __global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov6_derivs_kernel(const Rov6Dev* __restrict__ pg, int64_t n, const float* t,
-                                                                      const float* y_in, const float* sp_in, float* eold,
+                                                                      const float* y_in, const float* sp_in, const float* cur_in, float* eold,
                                                                       float* eint, float* told, const uint8_t* has_old,
                                                                       float* dy_out, float* aux_out) {
     const PP p = param_ptr<PP>(pg);
@@ -1332,7 +1334,8 @@ __global__ __launch_bounds__(MVRL_STEP_BLOCK) void rov6_derivs_kernel(const Rov6
         pid.eold[5] = angle_error(sp[5], y[5]);
     }
     float to = told[i];
-    Rhs6<SYM, false, PP> rhs{p, sp, &pid, &to, make_float2(0.f, 0.f), aux_out + i * 14};
+    const float2 cur = FLOW ? make_float2(cur_in[i * 2], cur_in[i * 2 + 1]) : make_float2(0.f, 0.f);
+    Rhs6<SYM, FLOW, PP> rhs{p, sp, &pid, &to, cur, aux_out + i * 14};
     rhs(t[i], y, dy);
 #pragma unroll
     for (int k = 0; k < 12; k++) dy_out[i * 12 + k] = dy[k];
@@ -1490,12 +1493,16 @@ hipError_t launch_rov6_unit(const Rov6Dev* p, bool baked, bool sym, int64_t n, c
 
 // ---- host-side launchers ---------------------------------------------------------------------------
 hipError_t launch_rov6_derivs(const Rov6Dev* p, bool baked, bool sym, int64_t n, const float* t, const float* y, const float* sp,
-                              float* eold, float* eint, float* told, const uint8_t* has_old, float* dy, float* aux,
+                              const float* cur, float* eold, float* eint, float* told, const uint8_t* has_old, float* dy, float* aux,
                               hipStream_t stream) {
     dim3 grid((unsigned)((n + MVRL_STEP_BLOCK - 1) / MVRL_STEP_BLOCK)), block(MVRL_STEP_BLOCK);
-    if (baked) hipLaunchKernelGGL((rov6_derivs_kernel<const Rov6Baked*, true>), grid, block, 0, stream, p, n, t, y, sp, eold, eint, told, has_old, dy, aux);
-    else if (sym) hipLaunchKernelGGL((rov6_derivs_kernel<CP6, true>), grid, block, 0, stream, p, n, t, y, sp, eold, eint, told, has_old, dy, aux);
-    else hipLaunchKernelGGL((rov6_derivs_kernel<CP6, false>), grid, block, 0, stream, p, n, t, y, sp, eold, eint, told, has_old, dy, aux);
+#define MVRL_D6(PPT, S, F) hipLaunchKernelGGL((rov6_derivs_kernel<PPT, S, F>), grid, block, 0, stream, p, n, t, y, sp, cur, eold, eint, told, has_old, dy, aux)
+    if (cur) {
+        if (baked) MVRL_D6(const Rov6Baked*, true, true); else if (sym) MVRL_D6(CP6, true, true); else MVRL_D6(CP6, false, true);
+    } else {
+        if (baked) MVRL_D6(const Rov6Baked*, true, false); else if (sym) MVRL_D6(CP6, true, false); else MVRL_D6(CP6, false, false);
+    }
+#undef MVRL_D6
     return hipGetLastError();
 }
 

@@ -20,6 +20,15 @@ def shard_range(n_global, rank, world_size):
     return offset, count
 
 
+def message_layout(n_global, world_size, obs_dim, reward_plane=True):
+    """The gather message of one rank and step (OutputGather; the C side's mvrl_group_message_layout is the same arithmetic):
+    obs[cmax, obs_dim] f32 | reward[cmax] f32 (if reward_plane) | done[cmax] u8, padded to 16 B; cmax = the largest shard."""
+    cmax = max(shard_range(n_global, r, world_size)[1] for r in range(world_size))
+    off_rew = cmax * int(obs_dim) * 4
+    off_done = off_rew + (cmax * 4 if reward_plane else 0)
+    return dict(cmax=cmax, off_reward=off_rew, off_done=off_done, msg_bytes=(off_done + cmax + 15) // 16 * 16)
+
+
 def init_from_env(backend=None):
     """Join the process group torchrun set up (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -53,13 +62,11 @@ class OutputGather:
         self.root, self.mode, self.group = root, mode, group
         self.n_global, self.obs_dim = int(n_global), int(obs_dim)
         self.ranges = [shard_range(n_global, r, self.world) for r in range(self.world)]
-        self.cmax = max(c for _, c in self.ranges)
         self.count = self.ranges[self.rank][1]
         self.device = device
         self.reward_plane = bool(reward_plane)
-        self.off_rew = self.cmax * self.obs_dim * 4
-        self.off_done = self.off_rew + (self.cmax * 4 if self.reward_plane else 0)
-        self.msg_bytes = (self.off_done + self.cmax + 15) // 16 * 16
+        lay = message_layout(n_global, self.world, obs_dim, self.reward_plane)
+        self.cmax, self.off_rew, self.off_done, self.msg_bytes = lay["cmax"], lay["off_reward"], lay["off_done"], lay["msg_bytes"]
         self.send = torch.zeros((self.msg_bytes,), dtype=torch.uint8, device=device)
         # without a reward plane: where the step kernel's (all-zero) reward output lands, and what receivers see
         self._rew_scratch = None if self.reward_plane else torch.zeros((self.cmax,), dtype=torch.float32, device=device)

@@ -14,7 +14,7 @@ import numpy as np
 
 MODEL_AUV, MODEL_ROV3, MODEL_ROV6 = 0, 1, 2
 CTRL_FAITHFUL, CTRL_ZOH = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 MODEL_NAMES = {"auv": MODEL_AUV, "rov3": MODEL_ROV3, "rov6": MODEL_ROV6}
 #            act, obs, init, state_words, aux

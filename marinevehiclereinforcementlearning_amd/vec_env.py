@@ -133,7 +133,7 @@ class MarineVecEnv:
     def reset(self, init=None):
         """All environments start a new episode.  `init` [N, init_dim] gives explicit initial values (see
         include/mvrl.h); otherwise they are drawn on the device (counter-based RNG keyed by seed and env id)."""
-        return self._h.reset(init=init).copy()
+        return self._h.reset(init=init)
 
     def step_async(self, actions):
         # not clipped here: the reference envs apply the raw action (6DoF.py:545-551)
@@ -144,7 +144,7 @@ class MarineVecEnv:
         self._pending = True
 
     def step_wait(self):
-        obs, rew, done = self._h.step(self._deferred) if self._h.f64 else self._h.step_wait()
+        obs, rew, done = self._h.step(self._deferred, copy=False) if self._h.f64 else self._h.step_wait(copy=False)   # copied below
         self._pending = False
         bits = done.copy()
         dones = bits != 0
@@ -204,11 +204,15 @@ class MarineVecEnv:
     def handle(self):
         return self._h
 
-    def get_state(self):
-        return self._h.get_state()
+    def get_state(self, raw=False):
+        """The SoA state planes (include/mvrl.h).  raw=True: verbatim, as the C ABI exchanges them - what a CHECKPOINT should keep: an
+        fp32 handle stores the Euler angles as 32-bit binary angles, and the default (decoded to fp32 radians, the reference's
+        convention) loses up to 2.4e-7 rad when it is encoded again by a later set_state on another handle or after another
+        get_state; the closed loop is chaotic, so only set_state(get_state(raw=True), raw=True) reproduces a run bit for bit."""
+        return self._h.get_state(raw=raw)
 
-    def set_state(self, st):
-        self._h.set_state(st)
+    def set_state(self, st, raw=False):
+        self._h.set_state(st, raw=raw)
 
     def _ensure_tensors(self):
         if self._tensors is None:

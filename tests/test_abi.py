@@ -208,12 +208,12 @@ def test_default_config_equals_make_config(lib):
     assert lib.mvrl_default_config(7, 1, C.byref(P.Config())) != 0 and lib.mvrl_default_config(2, 1, None) != 0
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="step_rov6"):
     import subprocess
-    exe = str(tmp_path / "step_rov6")
+    exe = str(tmp_path / name)
     pkg = os.path.join(REPO, "marinevehiclereinforcementlearning_amd")
-    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", "step_rov6.c"),
-                           "-L", pkg, "-lmvrl", f"-Wl,-rpath,{pkg}", "-o", exe])
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "examples", name + ".c"),
+                           "-L", pkg, "-lmvrl", "-lm", f"-Wl,-rpath,{pkg}", "-o", exe])
     return exe
 
 
@@ -226,3 +226,46 @@ def test_c_example_builds_against_the_header_and_fails_loudly_without_a_gpu(lib,
         pytest.skip("a GPU is present: tests/test_gpu_api.py runs the example for real")
     r = subprocess.run([exe, "64", "2"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "no HIP device" in r.stderr and "step" not in r.stdout
+    # examples/group_c5.c: BASELINE configs[4] from one C process (mvrl_group_*): same contract
+    exe = _build_c_example(tmp_path, "group_c5")
+    r = subprocess.run([exe, "64", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "no HIP device" in r.stderr and "env-steps/s" not in r.stdout
+
+
+def test_handle_outputs_are_copies_by_default():
+    """Lifetime contract of the Python wrapper: Handle.reset / step / step_wait hand out FRESH arrays unless the caller asks
+    for the zero-copy views of the handle's pinned staging block (copy=False), which die with the handle.  Checked on the signatures
+    here (no GPU); tests/test_gpu_api.py::test_outputs_outlive_the_handle checks the behaviour."""
+    import inspect
+    from marinevehiclereinforcementlearning_amd import _lib
+    for name in ("reset", "step", "step_wait"):
+        sig = inspect.signature(getattr(_lib.Handle, name))
+        assert sig.parameters["copy"].default is True, name
+
+
+def test_group_partition_and_message_layout_match_the_python_side(lib):
+    """mvrl_group_* cuts the batch and lays the gather message out exactly as distributed.shard_range / OutputGather do (both sides
+    of BASELINE configs[4] - one process per GPU over torch.distributed, or one process for all GPUs over the C ABI - exchange the
+    same bytes); without a GPU a group cannot be created and says so (no CPU fallback)."""
+    from marinevehiclereinforcementlearning_amd import distributed as D, group as G
+    for n, w in [(67, 8), (8 * 1048576, 8), (5, 5), (100, 3), (1, 1), (1000003, 7)]:
+        assert [G.shard_range(n, i, w) for i in range(w)] == [D.shard_range(n, i, w) for i in range(w)]
+        for obs_dim, rp in [(9, False), (11, True), (5, False)]:
+            assert G.message_layout(n, w, obs_dim, rp) == D.message_layout(n, w, obs_dim, rp)
+    # configs[4]: 8 x 1 048 576 6-DoF envs -> 37 B per env on the wire (obs 36 + done 1; the reward plane is identically 0)
+    lay = G.message_layout(8 * 1048576, 8, 9, False)
+    assert lay["msg_bytes"] == 1048576 * 37
+    with pytest.raises(_lib.MvrlError):
+        G.shard_range(10, 3, 3)
+    if lib.mvrl_device_count() == 0:
+        with pytest.raises(_lib.MvrlError, match="ENODEV"):
+            G.DeviceGroup(P.make_config("rov6", 128, use_flow=False), [0])
+    # bad arguments are refused before any device is touched
+    g = C.c_void_p()
+    cfg = P.make_config("rov6", 128, use_flow=False)
+    G._declare(lib)
+    assert lib.mvrl_group_create(C.byref(cfg), None, 1, 0, C.byref(g)) == -1
+    dev = (C.c_int32 * 2)(0, 0)
+    assert lib.mvrl_group_create(C.byref(cfg), dev, 2, 5, C.byref(g)) == -1
+    cfg64 = P.make_config("rov6", 128, use_flow=False, precision="f64")
+    assert lib.mvrl_group_create(C.byref(cfg64), dev, 2, 0, C.byref(g)) == -1

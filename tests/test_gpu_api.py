@@ -665,3 +665,92 @@ def test_c_example_runs_and_agrees_with_the_python_path(tmp_path):
         assert np.allclose(nums[:9], o[0], atol=1.5e-6), (t, nums[:9], o[0])
         assert abs(nums[9] - float(o.astype(np.float64).sum())) < 1e-3 * max(1.0, abs(nums[9])), (t, nums[9])
     h.close()
+
+
+def test_outputs_outlive_the_handle():
+    """`obs = Handle(cfg).reset()` must stay valid after the handle is gone: by default the wrapper returns copies, not views of the
+    pinned staging block that mvrl_destroy frees."""
+    import gc
+    cfg = P.make_config("rov6", 64, use_flow=False, seed=5)
+    h = _lib.Handle(cfg)
+    obs = h.reset()
+    o, r, d = h.step(np.zeros((64, 6), np.float32))
+    view = h.step(np.zeros((64, 6), np.float32), copy=False)[0]
+    assert obs.flags.owndata and o.flags.owndata and not view.flags.owndata
+    keep = (obs.copy(), o.copy(), r.copy(), d.copy())
+    h.close()
+    del h, view
+    gc.collect()
+    h2 = _lib.Handle(P.make_config("rov6", 64, use_flow=False, seed=6))     # reuses freed memory if anything was dangling
+    h2.reset()
+    assert np.array_equal(obs, keep[0]) and np.array_equal(o, keep[1]) and np.array_equal(r, keep[2]) and np.array_equal(d, keep[3])
+    h2.close()
+
+
+def test_group_c_example_runs_on_shards_of_one_card(tmp_path):
+    """examples/group_c5.c - BASELINE configs[4] from plain C in one process - with three shards on the box's only card (the
+    device-to-device transport) and small shards: both passes (outputs left on the shards / gathered to the root every step) run."""
+    import subprocess
+    from .test_abi import _build_c_example
+    exe = _build_c_example(tmp_path, "group_c5")
+    r = subprocess.run([exe, "4096", "30", "3", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-500:])
+    assert "group of 3 device(s)" in r.stdout and "device-to-device copy" in r.stdout and r.stdout.count("env-steps/s") == 2
+    assert "global envs [8192, 12288)" in r.stdout and "37.0 B per env" in r.stdout
+
+
+# ---- several devices behind one object (mvrl_group_*) ------------------------------------------------------------------------
+@pytest.mark.parametrize("model,devices", [("rov6", [0]), ("rov6", [0, 0]), ("auv", [0, 0, 0]), ("rov3", [0, 0])])
+def test_device_group_equals_the_unsharded_batch(model, devices):
+    """A group steps its shards (one launch per device, no host sync), gathers their messages to the root and hands out the global
+    batch: bit for bit what ONE plain handle of the whole batch produces - for a group of one device and for shards that share
+    the box's only card (device-to-device transport; RCCL refuses duplicate devices, the 8-GPU transport is the driver's to run).
+    Random resets are Philox-keyed by the global env id; actions reach the shards through the root scatter."""
+    from marinevehiclereinforcementlearning_amd.group import DeviceGroup
+    n = 64 * 5 + 7                                     # ragged: shards of different sizes
+    flow = None
+    kw = dict(seed=77, max_steps=6, auto_reset=True)
+    if model == "auv":
+        flow = ReconstructedFlow.synthetic(n_modes=4, n_time=64)
+        flow.scale(11., 1., 2., translate=(-1.65, -1.1))
+        kw["dt"] = 0.02
+    cfg = P.make_config(model, n, use_flow=flow is not None, **kw)
+    g = DeviceGroup(cfg, devices)
+    h = _lib.Handle(P.make_config(model, n, use_flow=flow is not None, **kw))
+    if flow is not None:
+        g.set_flow(flow.table_uv(), flow.dt, flow.dx, flow.dy)
+        h.set_flow(flow.table_uv(), flow.dt, flow.dx, flow.dy)
+    from marinevehiclereinforcementlearning_amd.distributed import shard_range
+    assert g.transport == "copy" and g.ranges == [shard_range(n, i, len(devices)) for i in range(len(devices))]
+    obs0 = h.reset()
+    g.reset()
+    g.gather_dev()
+    o, r, d = g.download()
+    assert np.array_equal(o, obs0) and not d.any()
+    rng = np.random.default_rng(5)
+    act_dim = g.act_dim
+    a_dev = torch.empty((n, act_dim), dtype=torch.float32, device="cuda:0")
+    for s in range(14):                                # crosses two auto-resets (max_steps = 6)
+        a = rng.uniform(-1, 1, (n, act_dim)).astype(np.float32)
+        a_dev.copy_(torch.from_numpy(a))
+        torch.cuda.synchronize()
+        g.scatter_actions_dev(a_dev.data_ptr())
+        g.step_dev()
+        g.gather_dev()
+        o, r, d = g.download()
+        ho, hr, hd = h.step(a)
+        assert np.array_equal(o, ho) and np.array_equal(r, hr) and np.array_equal(d, hd), (model, devices, s)
+    # the shards' state planes together are the unsharded state
+    st = np.concatenate([g.shard(i).get_state(raw=True) for i in range(len(devices))], axis=1)
+    assert np.array_equal(st.view(np.uint32), h.get_state(raw=True).view(np.uint32))
+    # per-shard action pointers instead of the root scatter, and the overlap protocol: step k+1 is enqueued before gather k is awaited
+    parts = [a_dev[f:f + c] for f, c in g.ranges]
+    g.step_dev([p.data_ptr() for p in parts])
+    g.gather_dev()
+    g.step_dev([p.data_ptr() for p in parts])
+    o1 = g.download()[0]
+    g.gather_dev()
+    o2 = g.download()[0]
+    assert np.array_equal(o1, h.step(a)[0]) and np.array_equal(o2, h.step(a)[0])
+    g.close()
+    h.close()

@@ -641,6 +641,29 @@ def test_masked_reset_and_state_roundtrip():
     assert np.all(st2[-1].view(np.int32)[mask == 1] == 0)
     h.set_state(st)
     assert np.array_equal(h.get_state(), st)
+    # a CHECKPOINT is the raw planes: the decoded default re-encodes the binary angles from fp32 radians after the intervening
+    # get_state above (up to 2.4e-7 rad), the raw planes restore the bit patterns themselves - also on ANOTHER handle
+    raw = h.get_state(raw=True)
+    for _ in range(2):
+        h.step(a)
+    h.get_state()
+    h.set_state(raw, raw=True)
+    assert np.array_equal(h.get_state(raw=True).view(np.uint32), raw.view(np.uint32))
+    h2 = _lib.Handle(P.make_config("rov3", n, auto_reset=False, seed=99, use_flow=False))
+    h2.reset()
+    h2.set_state(raw, raw=True)
+    assert np.array_equal(h2.get_state(raw=True).view(np.uint32), raw.view(np.uint32))
+    o1, o2 = h.step(a), h2.step(a)
+    assert np.array_equal(o1[0], o2[0]) and np.array_equal(h.get_state(raw=True).view(np.uint32), h2.get_state(raw=True).view(np.uint32))
+    h2.close()
+    # a second step_async while one is pending is refused before its actions are staged over the pending step's
+    h.set_state(raw, raw=True)
+    h.step_async(a)
+    with pytest.raises(_lib.MvrlError):
+        h.step_async(-a)
+    pending = h.step_wait()
+    h.set_state(raw, raw=True)
+    assert np.array_equal(pending[0], h.step(a)[0])
     with pytest.raises(_lib.MvrlError):
         h.lib  # noqa: B018
         _lib.check(h.lib.mvrl_step_wait(h.h, None, None, None), h.h)  # step_wait without step_async -> ESTATE

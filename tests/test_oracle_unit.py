@@ -113,6 +113,24 @@ def test_derivs(o64, dof):
     assert worst < 1e-9, worst
 
 
+@pytest.mark.parametrize("dof", [6, 3])
+def test_derivs_with_current(o64, dof):
+    """The 3/6-DoF + turbulence composition's right-hand side, pinned by EXECUTING the reference with a non-zero current (G21:
+    3DoF.py:182-191, :216-239, :279 unedited; G22: 6DoF.py:258-267, :396, hook-assisted - see each fixture's `how`): the oracle's
+    `cur != 0` branches (rhs3_given_rpm / rhs6_given_rpm + orc_force_model6) against what the reference's own lines computed."""
+    g = golden("g21_derivs3_current.npz" if dof == 3 else "g22_derivs6_current.npz")
+    worst, acted = 0.0, 0.0
+    for i in range(len(g["t"])):
+        pid = o64.make_pid(g["eOld"][i] if g["has_old"][i] else None, g["eInt"][i], g["tOld"][i])
+        dy, gcf, rpm = o64.derivs(dof, g["t"][i], g["y"][i], g["sp"][i], pid, cur=g["cur"][i])
+        worst = max(worst, max_scaled_err(dy, g["dy"][i]), max_scaled_err(gcf, g["gcf"][i]), max_scaled_err(rpm, g["rpm"][i]))
+        acted = max(acted, max_scaled_err(g["dy"][i], g["dy_zero_current"][i]))
+        assert max_scaled_err(np.array(pid.eold)[:dof], g["eOld_out"][i]) < 1e-13
+        assert max_scaled_err(np.array(pid.eint)[:dof], g["eInt_out"][i]) < 1e-12
+    assert worst < 1e-9, worst
+    assert acted > 1e-2      # the fixture does exercise the branch
+
+
 def test_anchors(o64):
     """Known-answer anchors quoted in SURVEY.md 8(a)."""
     g = golden("g00_anchors.npz")

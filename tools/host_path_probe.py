@@ -9,11 +9,11 @@ for model, n in [("rov6", 262144), ("rov6", 1048576), ("rov3", 65536)]:
     h.reset()
     a = np.random.default_rng(0).uniform(-1, 1, size=(n, h.act_dim)).astype(np.float32)
     for _ in range(3):
-        h.step(a)
+        h.step(a, copy=False)
     t0 = time.perf_counter()
     K = 20
     for _ in range(K):
-        h.step(a)
+        h.step(a, copy=False)
     dt = (time.perf_counter() - t0) / K
     print(f"host-buffer mvrl_step {model} n={n}: {dt*1e3:.3f} ms/step -> {n/dt:.3e} env-steps/s "
           f"({(h.act_dim*4 + h.obs_dim*4 + 5) * n / dt / 1e9:.1f} GB/s over PCIe incl. staging memcpy)")

@@ -22,7 +22,7 @@ for n in (1, 16, 64, 1024, 16384):
     h = _lib.Handle(P.make_config("rov6", n, seed=1, use_flow=False))
     h.reset()
     a = np.random.default_rng(0).uniform(-1, 1, size=(n, 6)).astype(np.float32)
-    t_abi = timeit(lambda: h.step(a))
+    t_abi = timeit(lambda: h.step(a, copy=False))
     h.close()
     env = MarineVecEnv("rov6", n, seed=1)
     env.reset()

@@ -18,10 +18,12 @@ ARGS="$ROOT/bench.py --workload $WL --no-cpu-baseline $*"
 PMC_ARGS="$ARGS --chains 1 --steps 200 --warmup 20 --repeats 1 --prewarm-s 0.2"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_kt -- python3 $ARGS --launch chains > $OUT/prof_${TAG}_kt.json 2> $OUT/prof_${TAG}_kt.err
 rc=$?; echo "kt rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
+python3 $ROOT/tools/trace_median.py $OUT/prof_${TAG}_kt      # per-kernel median / p10 / p90 before the trace goes
 find $OUT/prof_${TAG}_kt -name "*_kernel_trace.csv" -delete     # the per-dispatch trace of a 10k-launch run is large: keep the stats tables
 # the same bench command with one launch per step: its per-kernel average is what bench.py's roofline.single_launch reports
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_kt1 -- python3 $ARGS --chains 1 > $OUT/prof_${TAG}_kt1.json 2> $OUT/prof_${TAG}_kt1.err
 rc=$?; echo "kt1 rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi
+python3 $ROOT/tools/trace_median.py $OUT/prof_${TAG}_kt1
 find $OUT/prof_${TAG}_kt1 -name "*_kernel_trace.csv" -delete
 if [ "${MVRL_PROFILE_PMC:-1}" = "0" ]; then tail -c 300 $OUT/prof_${TAG}_kt.json; exit 0; fi   # kernel-trace passes only
 i=0

@@ -73,6 +73,15 @@ def main():
             if kernel_substr in r[0]:
                 calls1, avg1_ns = int(r[1]), float(r[3])
                 break
+    def medians(which):
+        """median / p10 / p90 of the step kernel's dispatch durations (tools/trace_median.py, written before the trace was deleted)"""
+        f = os.path.join(OUT, f"prof_{tag}_{which}", "kernel_medians.json")
+        if not os.path.exists(f):
+            return None
+        for k, v in json.load(open(f)).items():
+            if kernel_substr in k:
+                return {"median_us": v["median_ns"] / 1e3, "p10_us": v["p10_ns"] / 1e3, "p90_us": v["p90_ns"] / 1e3, "calls": v["calls"]}
+        return None
     c, cnt, dur_ns = counters(tag, kernel_substr)
     waves = c.get("SQ_WAVES") or (n_envs / 64.0)
     ent = {"tag": tag, "kernel": kernel_substr, "envs": n_envs, "launches_averaged": cnt,
@@ -80,6 +89,8 @@ def main():
            "bench_command_note": "default bench: 2 chains, each launch covers half the batch and two launches are in flight at any time, "
                                  "so a launch lasts about one whole step",
            "chains1_kernel_avg_us": None if avg1_ns is None else avg1_ns / 1e3, "chains1_kernel_calls": calls1,
+           "bench_command_kernel_median": medians("kt"), "chains1_kernel_median": medians("kt1"),
+           "median_note": "the --stats average is moved by a few long dispatches (first launches, clock ramps); the MEDIAN is what compares with bench.py's median region",
            "counter_pass_launch": "one launch per env step (--chains 1), 200 steps", "raw": c,
            "algorithmic_read_bytes_per_env": alg_read, "algorithmic_bytes_per_env": alg_bytes}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:

@@ -15,6 +15,8 @@ VARIANTS = {
     "f64strict": dict(extra=[], drop=(), f64=["-ffp-contract=off"]),
     "f64fast": dict(extra=[], drop=(), f64=["-ffast-math"]),
     "f64nopark": dict(extra=["-DMVRL_NO_PARK"], drop=()),
+    "f64ilp": dict(extra=[], drop=(), f64=["-ffp-contract=fast", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+    "f64occ": dict(extra=[], drop=(), f64=["-ffp-contract=fast", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]),
     "f64fulltrig": dict(extra=["-DMVRL_FULL_STAGE_TRIG"], drop=()),
     # attribution (tests/audit/episode_audit.py): the round-4 fp32 turbulence sample time
     "flowt32": dict(extra=["-DMVRL_FLOW_TIME_F32"], drop=()),
