@@ -63,7 +63,11 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 RING = 8
 N_SIMD = 256 * 4        # CUs x SIMDs
-VALU_PEAK = 1.2         # wave64 VALU instructions / ns / SIMD: one per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
+VALU_PEAK = 1.2         # wave64 fp32 FMAs / ns / SIMD the SPEC implies (157.3 TFLOP/s: packed, 2.4 GHz - MI355X_MICROARCH.md)
+# What the VALU SUSTAINS per opcode under the board's power cap, measured with inline-asm chains (tools/valu_ops.hip,
+# profiles/r05_valu_ops.txt; wave-instructions / ns / SIMD at 4 waves per SIMD): scalar v_fma/mul/add_f32 0.81, v_pk_fma_f32 0.49
+# (= 0.97 fma), v_max/med3/cmp/cvt_f32 and an fma with an SGPR operand 0.53-0.57, v_rcp_f32 0.29, v_fma_f64 0.44-0.47.
+VALU_SUSTAINED_FMA = {"f32": 0.805, "f64": 0.455}
 XGMI_LINK_GBS = 76.8  # one xGMI link, one direction (7 links x ~153 GB/s bidirectional per GPU)
 
 
@@ -532,7 +536,11 @@ def main():
                         # achieved VALU issue rate of THIS run from the committed instruction count and the live time
                         wave_instr = v["wave_instr_per_env_step"] * n / 64.0
                         rate = wave_instr / (per_step_s * 1e9) / N_SIMD          # wave-instr / ns / SIMD
+                        sus = VALU_SUSTAINED_FMA[args.precision]
                         v.update({"achieved": rate, "peak": VALU_PEAK, "unit": "wave-instr/ns/SIMD", "frac": rate / VALU_PEAK,
+                                  "sustained_fma_issue": sus, "frac_of_sustained_fma_issue": rate / sus,
+                                  "sustained_note": "measured issue rate of an all-FMA instruction stream of this precision under the power cap "
+                                                    "(tools/valu_ops.hip, profiles/r05_valu_ops.txt); min / max / compare / convert cost 1.5 x an fp32 FMA",
                                   "flops_per_env_step": v.get("flops_per_env_step"),
                                   "achieved_TFLOPs": (v.get("flops_per_env_step") or 0) * n / per_step_s / 1e12})
                         valu = v
@@ -594,9 +602,9 @@ def main():
                          "note": ("fused episodes: the bytes are the turbulence gathers (L2 / Infinity-Cache resident), the kernel is "
                                   "bound by instruction issue, not HBM" if pd_obj is not None else
                                   auv_note if wl["model"].startswith("auv") else
-                                  "this kernel is bound by board power at the VALU (time follows the executed-instruction count - `valu` - "
-                                  "and the operands' switching: DESIGN.md section 5), not by HBM; the HBM fraction is reported as the "
-                                  "contract asks") + "; kernel_us_per_step = HIP-event time of the median K-step region / K "
+                                  "this kernel is bound by VALU instruction issue under the board's power cap (time follows the executed-"
+                                  "instruction count - `valu` - at the per-opcode rates of profiles/r05_valu_ops.txt: DESIGN.md section 5), "
+                                  "not by HBM; the HBM fraction is reported as the contract asks") + "; kernel_us_per_step = HIP-event time of the median K-step region / K "
                                  "(wall time on the GPU: launch gaps, ramps and tails included)"},
             "outputs_finite": finite,
         }

@@ -104,3 +104,42 @@ class ChainStepper:
                 launch(lo, cnt, *ptrs, s.cuda_stream)
         self.join()
         return obs, rew, done, actions
+
+    def capture_closed_loop(self, policy, steps, actions=None, joined=False):
+        """The closed loop captured ONCE into a HIP graph: `graph.replay()` then runs `steps` env steps with the policy in the loop
+        and no host work at all - neither Python's launch overhead, which makes the eager per-chain loops useless
+        (profiles/r03_policy_loop.txt), nor the command processor's dependent-launch gap between the small policy kernels.
+        One branch of the graph per chain (its own capture stream: policy(A) and step(A) overlap step(B)); joined=True captures
+        the single-stream loop `a = policy(obs); obs = step(a)` instead, for comparison.  Replays are exact continuations: the
+        env's RNG position lives in its state planes, the policy reads the observation tensors the previous replay left.
+        Returns (graph, (obs, reward, done, actions)); the policy must not allocate differently between capture and replay (any
+        eager torch module or the mvrl_policy_* kernels)."""
+        env = self.env
+        obs, rew, done = env._ensure_tensors()
+        rt = torch.float64 if env.handle.f64 else torch.float32
+        n, ad = env.num_envs, env.action_space.shape[0]
+        if actions is None:
+            actions = torch.empty((n, ad), dtype=rt, device=obs.device)
+        ptrs = (actions.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr())
+        launch = env.handle.step_range_dev
+        cap = torch.cuda.Stream(device=obs.device)
+        cap.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=cap):
+            cur = torch.cuda.current_stream()
+            if joined:
+                for _ in range(int(steps)):
+                    actions.copy_(policy(obs))
+                    env.handle.step_dev(*ptrs, cur.cuda_stream)
+            else:
+                for s in self.streams:
+                    s.wait_stream(cur)
+                for _ in range(int(steps)):
+                    for (lo, cnt), s in zip(self.ranges, self.streams):
+                        with torch.cuda.stream(s):
+                            actions[lo:lo + cnt].copy_(policy(obs[lo:lo + cnt]))
+                        launch(lo, cnt, *ptrs, s.cuda_stream)
+                for s in self.streams:
+                    cur.wait_stream(s)
+        env.handle.count_launches(0)
+        return graph, (obs, rew, done, actions)

@@ -28,7 +28,7 @@ __device__ __forceinline__ void control3(PP p, const float* z, Pid3& s, float dt
     p = launder(p);
     float e[3] = {z[0], z[1], 0.f}, z2 = z[2];
     if (fixed) { e[0] += e0[0]; e[1] += e0[1]; z2 += e0[2]; }
-#if !MVRL_F64 && !defined(MVRL_NO_YAW_INC)
+#if !defined(MVRL_NO_YAW_INC)
     // yaw error carried from call to call inside an env step (see pid6): previous error minus the yaw increment, wrapped
     float yaw_w = 0.f;
     if (USE_INC && inc_valid) {
@@ -137,14 +137,22 @@ __device__ __forceinline__ Trig1 trig1(float a) {
 // sin / cos of the heading at an RK stage that differs from a known one by the small increment d (stage_trig in mvrl_rov6.hip):
 // rotation by short Taylor polynomials; a lane with |d| > 0.25 (and the fp64 build) evaluates sp_psi - z_psi in full.
 __device__ __forceinline__ Trig1 stage_trig1(const Trig1& b, float d, float sp_psi, float z_psi) {
-#if MVRL_F64 || defined(MVRL_FULL_STAGE_TRIG)
+#if defined(MVRL_FULL_STAGE_TRIG)
     return trig1(sp_psi - z_psi);
 #else
     const float r2 = d * d;
+#if MVRL_F64
+    // fp64: Taylor to d^11 / d^12 - truncation 2.4e-18 / 4e-20 at |d| = 0.25 (stage_trig in mvrl_rov6.hip)
+    const float ps = fmaf(fmaf(fmaf(fmaf(-2.5052108385441720e-8f, r2, 2.7557319223985893e-6f), r2, -1.9841269841269841e-4f), r2, 8.3333333333333332e-3f), r2, -1.6666666666666666e-1f);
+    const float sd = fmaf(ps * r2, d, d);
+    const float pc = fmaf(fmaf(fmaf(fmaf(2.0876756987868099e-9f, r2, -2.7557319223985888e-7f), r2, 2.4801587301587302e-5f), r2, -1.3888888888888889e-3f), r2, 4.1666666666666664e-2f);
+    const float cd = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+#else
     const float ps = fmaf(8.333333333e-3f, r2, -1.666666667e-1f);
     const float sd = fmaf(ps * r2, d, d);
     const float pc = fmaf(-1.388888889e-3f, r2, 4.166666667e-2f);
     const float cd = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+#endif
     Trig1 t;
     t.s = fmaf(b.c, sd, b.s * cd);
     t.c = fmaf(-b.s, sd, b.c * cd);

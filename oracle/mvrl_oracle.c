@@ -273,7 +273,11 @@ static double noise_u(uint64_t* st) {   /* splitmix64 -> U(-1, 1) */
  *   1: every RHS output (dy) rounded to fp32 - the least any fp32 right-hand side commits (one rounding of each result)
  *   2: the turbulence sample time formed in fp32, as the round-4 kernels did (flow_gather of that round)
  *   4: the sampled current (u_c, v_c) rounded to fp32
- *   8: the state rounded to fp32 after every RK4 sub-step (instead of once per env step, which the callers do on the arrays) */
+ *   8: the state rounded to fp32 after every RK4 sub-step (instead of once per env step, which the callers do on the arrays)
+ *  16: forceModel + M^-1 + J (everything of derivs after the allocation) evaluated in fp32 ARITHMETIC by the fp32 build of this
+ *      file on fp32-rounded inputs, its result widened again: what the plain fp32 formulation of the right-hand side commits
+ *      with exact state, exact controller and exact allocation
+ *  32: the same for allocateThrust (body-frame demand, pinv(A) product, rpm map) */
 static int FN(g_emulate) = 0;
 void FN(orc_set_emulate)(int mask) { FN(g_emulate) = mask; }
 static inline real emu_round(real x) { return (real)(float)x; }
@@ -309,6 +313,16 @@ static void rhs6_given_rpm(const mvrl_rov6_params* P, const real y[12], const re
     }
 }
 
+void FN(orc_rhs6_given_rpm)(const mvrl_rov6_params* P, const real y[12], const real axes[9], const real rpm_in[8], const real cur_glob[2],
+                            real dy[12]) {
+    rhs6_given_rpm(P, y, axes, rpm_in, cur_glob, dy);
+}
+#if defined(ORC_IS_F64)
+void orc_rhs6_given_rpm_f32(const mvrl_rov6_params*, const float*, const float*, const float*, const float*, float*);
+void orc_alloc6_f32(const mvrl_rov6_params*, const float*, const float*, float*);
+void orc_body_axes_f32(const float*, float*);
+#endif
+
 /* BlueROV2Heavy6DoF.derivs (6DoF.py:406-442) */
 void FN(orc_derivs6)(const mvrl_rov6_params* P, double t, const real y[12], const real sp[6], pid_t_* pid,
                      const real cur_glob[2], real dy[12], real gcf[6], real rpm[8]) {
@@ -327,6 +341,29 @@ void FN(orc_derivs6)(const mvrl_rov6_params* P, double t, const real y[12], cons
         }
     }
     FN(orc_pid6)(P, sp, y, t, pid, gcf);
+#if defined(ORC_IS_F64)
+    if (FN(g_emulate) & (16 | 32)) {   /* attribution only: parts of the right-hand side in fp32 arithmetic (see orc_set_emulate) */
+        float yf[12], af[9], gf[6], rf[8], cf[2] = {0, 0}, df[12];
+        for (int i = 0; i < 12; i++) yf[i] = (float)y[i];
+        for (int i = 0; i < 6; i++) gf[i] = (float)gcf[i];
+        orc_body_axes_f32(yf + 3, af);
+        if (FN(g_emulate) & 32) {
+            orc_alloc6_f32(P, af, gf, rf);
+            for (int i = 0; i < 8; i++) rpm[i] = rf[i];
+        } else {
+            FN(orc_alloc6)(P, axes, gcf, rpm);
+            for (int i = 0; i < 8; i++) rf[i] = (float)rpm[i];
+        }
+        if (FN(g_emulate) & 16) {
+            if (cur_glob) { cf[0] = (float)cur_glob[0]; cf[1] = (float)cur_glob[1]; }
+            orc_rhs6_given_rpm_f32(P, yf, af, rf, cf, df);
+            for (int i = 0; i < 12; i++) dy[i] = df[i];
+        } else {
+            rhs6_given_rpm(P, y, axes, rpm, cur_glob, dy);
+        }
+        return;
+    }
+#endif
     FN(orc_alloc6)(P, axes, gcf, rpm);
     rhs6_given_rpm(P, y, axes, rpm, cur_glob, dy);
 }

@@ -49,6 +49,9 @@ SWITCHES = [
     ("only the turbulence SAMPLE TIME formed in fp32 (round-4 kernels)", 2, ()),
     ("only the sampled current rounded to fp32", 4, ()),
     ("only every RHS OUTPUT rounded to fp32 (state exact: the least an fp32 right-hand side commits)", 1, ()),
+    ("forceModel + M^-1 + J in fp32 ARITHMETIC (fp32 build of the oracle), state / controller / allocation exact", 16, ()),
+    ("allocateThrust in fp32 arithmetic, everything else exact", 32, ()),
+    ("allocation + forceModel + M^-1 + J in fp32 arithmetic, state and controller exact", 16 | 32, ()),
     ("RHS outputs fp32 + state fp32 after every sub-step (an fp32 integrator at its best)", 1 | 8, ()),
     ("RHS outputs + sample time + current + plain fp32 storage", 1 | 2 | 4, ("pose", "ang", "vel", "pid", "sp")),
 ]
@@ -112,7 +115,7 @@ def main():
             print(f"#   step {s + 1}: " + " ".join(f"{v:.2f}" for v in rows[s + 1]) + f"   [{time.time() - t0:.0f} s]", flush=True)
     print("switch | % of envs beyond 1e-5 at step " + " / ".join(str(c) for c in CHECK if c <= steps) + " | median err at the last step")
     for k, (name, mask, classes) in enumerate(SWITCHES):
-        print(f"{name:100s} | " + " / ".join(f"{rows[c][k]:6.2f}" for c in CHECK if c <= steps) + f" | {med[k]:.2e}")
+        print(f"{name:112s} | " + " / ".join(f"{rows[c][k]:6.2f}" for c in CHECK if c <= steps) + f" | {med[k]:.2e}")
 
 
 if __name__ == "__main__":

@@ -86,6 +86,39 @@ def test_closed_loop_with_a_policy_per_chain(model, n, chains):
     ea.close(); eb.close()
 
 
+@pytest.mark.parametrize("model,n,joined", [("rov6", 8192 + 77, False), ("rov6", 4096, True), ("auv", 6000, False)])
+def test_closed_loop_captured_into_a_hip_graph(model, n, joined):
+    """ChainStepper.capture_closed_loop: the policy -> step loop (one graph branch per chain, or the joined single-stream loop)
+    captured ONCE and replayed: 3 replays of 7 steps == 21 eager steps of the joined loop, bit for bit, auto-resets included
+    (the env's RNG position lives in its state planes, so a replay is the exact continuation)."""
+    import torch
+    from marinevehiclereinforcementlearning_amd.chains import ChainStepper
+    from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv
+    kw = dict(seed=3, maxSteps=8, infos="lean")
+    ea, eb = MarineVecEnv(model, n, flow=_flow(), **kw), MarineVecEnv(model, n, flow=_flow(), **kw)
+    ad, od = ea.action_space.shape[0], ea.observation_space.shape[0]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    w = torch.rand((1, ad), device="cuda", generator=g) * 4 - 2
+
+    def policy(obs):
+        return torch.tanh(obs[:, :ad] * w + obs[:, od - ad:] * 0.5)
+    oa = ea.reset_tensors()
+    for k in range(21):
+        a_ref = policy(oa)
+        oa, ra, da = ea.step_tensors(a_ref.contiguous())
+    st = ChainStepper(eb, n_chains=2)
+    graph, (ob, rb, db, a_last) = st.capture_closed_loop(policy, 7, joined=joined)     # nothing runs during capture
+    eb.reset_tensors()                      # ONE reset, like ea (an env's episode counter keys its Philox stream)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(a_ref, a_last)
+    assert np.array_equal(ea.get_state(), eb.get_state())
+    assert int(ea.handle.episode_counter().max()) >= 3
+    ea.close(); eb.close()
+
+
 def test_range_arguments_are_checked():
     h = _lib.Handle(P.make_config("rov6", 1000, auto_reset=False, max_steps=10))
     a = h.dev_alloc(1000 * 6 * 4); o = h.dev_alloc(1000 * 9 * 4); r = h.dev_alloc(4000); d = h.dev_alloc(1000)
@@ -131,17 +164,24 @@ def test_delay_kernel_holds_its_stream_and_always_ends():
         h.delay_dev(10001, None)
     with pytest.raises(_lib.MvrlError):
         h.delay_dev(-1, None)
-    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
-    e0, e1, f0, f1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+    # HIP maps streams onto a few hardware queues (4 by default), round-robin over every stream the PROCESS ever created: two
+    # streams that share a queue serialise.  Four candidates for "another stream": at least one sits on another queue than s0.
+    s0, others = torch.cuda.Stream(), [torch.cuda.Stream() for _ in range(4)]
+    e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+    f = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in others]
     h.delay_dev(200, s0.cuda_stream)                     # warm-up (first launch of the kernel)
     torch.cuda.synchronize()
-    e0.record(s0); f0.record(s1)
+    e0.record(s0)
+    for (fa, _), s in zip(f, others):
+        fa.record(s)
     h.delay_dev(3000, s0.cuda_stream)
-    e1.record(s0); f1.record(s1)
+    e1.record(s0)
+    for (_, fb), s in zip(f, others):
+        fb.record(s)
     t0 = time.perf_counter()
     torch.cuda.synchronize()
     assert time.perf_counter() - t0 < 1.0                # it ended
     assert 2.5 < e0.elapsed_time(e1) < 6.0               # ms: the stream was held for about 3 ms
-    assert f0.elapsed_time(f1) < 1.0                     # the other stream did not wait
+    assert min(fa.elapsed_time(fb) for fa, fb in f) < 1.0   # another stream did not wait
     h.delay_dev(0, s0.cuda_stream)                       # no-op
     h.close()

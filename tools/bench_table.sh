@@ -21,6 +21,10 @@ run --workload c4 --steps 20 --warmup 5
 run --workload c4 --control-mode zoh
 run --workload c4 --n-substeps 8
 run --workload c4 --precision f64 --steps 400 --warmup 40
+run --workload c3 --precision f64 --steps 400 --warmup 40
+run --workload c2 --precision f64 --steps 400 --warmup 40
+run --workload c4in
+run --workload c4in --chains 1
 run --workload c4 --flavour ctrl
 run --workload c4 --flavour sym
 run --workload c4 --flavour generic

@@ -4,6 +4,8 @@ step's observations, as in any RL roll-out.  Compares, for the BASELINE workload
 
     joined   : a = policy(obs); obs = env.step_tensors(a)          - one stream, the SB3-shaped loop
     chains   : ChainStepper.closed_loop(policy, K)                  - one policy -> step loop per lane range, on its own stream
+    joined-g : the joined loop captured into a HIP graph of 8 steps (ChainStepper.capture_closed_loop(joined=True)), replayed
+    chains-g : the per-chain loops captured into ONE HIP graph with a branch per chain, replayed - no host work in the loop
 
 with two policies: "elementwise" (4 small torch kernels on the observation) and "mlp" (obs -> 64 tanh -> act, torch matmuls).
 Results are identical between the two loops (tests/test_gpu_chains.py); this prints microseconds per env step of the whole batch."""
@@ -19,7 +21,7 @@ from marinevehiclereinforcementlearning_amd.vec_env import MarineVecEnv  # noqa:
 
 
 def main():
-    K = 1500
+    K = 1504
     for name, model, n, use_flow in (("c4", "rov6", 1048576, True), ("c3", "rov6", 262144, False), ("auv", "auv", 1048576, True)):
         flow = None
         if use_flow:
@@ -35,13 +37,20 @@ def main():
                     "mlp 64": lambda o: torch.tanh(torch.tanh(o @ w1) @ w2)}
         for pname, policy in policies.items():
             res = {}
-            for plan in ("joined", "chains", "joined", "chains"):
+            G = 8
+            for plan in ("joined", "chains", "joined-g", "chains-g", "joined", "chains", "joined-g", "chains-g"):
                 obs = env.reset_tensors()
                 st = ChainStepper(env, n_chains=2)
+                graph = None
+                if plan.endswith("-g"):
+                    graph, _ = st.capture_closed_loop(policy, G, joined=plan == "joined-g")
 
                 def run(k):
                     nonlocal obs
-                    if plan == "joined":
+                    if graph is not None:
+                        for _ in range(k // G):
+                            graph.replay()
+                    elif plan == "joined":
                         for _ in range(k):
                             obs, _, _ = env.step_tensors(policy(obs).contiguous())
                     else:
@@ -60,9 +69,10 @@ def main():
                 a = policy(obs)
             torch.cuda.synchronize()
             tp = (time.perf_counter() - t0) / K * 1e6
-            j, c = min(res["joined"]), min(res["chains"])
-            print(f"{name:4s} {n:8d} envs, policy {pname:12s} ({tp:5.1f} us alone): joined {j:7.1f} us/step   per-chain loops {c:7.1f} us/step   "
-                  f"({100 * (1 - c / j):.0f} % less)  = {n / c * 1e6:.3e} env-steps/s closed loop", flush=True)
+            j, c, jg, cg = min(res["joined"]), min(res["chains"]), min(res["joined-g"]), min(res["chains-g"])
+            print(f"{name:4s} {n:8d} envs, policy {pname:12s} ({tp:5.1f} us alone): eager joined {j:7.1f} / per-chain {c:7.1f} us/step | "
+                  f"HIP graph of {G} steps: joined {jg:7.1f} / per-chain branches {cg:7.1f} us/step ({100 * (1 - cg / jg):.0f} % less than the joined graph, "
+                  f"{100 * (1 - cg / j):.0f} % less than the eager joined loop) = {n / min(c, cg, j, jg) * 1e6:.3e} env-steps/s closed loop", flush=True)
         env.close()
 
 

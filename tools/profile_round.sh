@@ -28,7 +28,8 @@ find $OUT/prof_${TAG}_kt1 -name "*_kernel_trace.csv" -delete
 if [ "${MVRL_PROFILE_PMC:-1}" = "0" ]; then tail -c 300 $OUT/prof_${TAG}_kt.json; exit 0; fi   # kernel-trace passes only
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
-           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32" "GRBM_GUI_ACTIVE"; do
+           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32" \
+           "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/prof_${TAG}_pmc$i -- python3 $PMC_ARGS > $OUT/prof_${TAG}_pmc$i.json 2> $OUT/prof_${TAG}_pmc$i.err
   rc=$?; echo "pmc group $i ($grp) rc=$rc"; if [ $rc -ge 124 ]; then exit $rc; fi

@@ -17,6 +17,9 @@ profiles)
   done
   bash tools/profile_round.sh auv ${R}_auv4m --envs-per-gpu 4194304 > gpurun_out/prof_${R}_auv4m.log 2>&1; rc=$?; echo "auv4m rc=$rc"; cd $ROOT
   if [ $rc -ge 124 ]; then exit $rc; fi
+  bash tools/profile_round.sh c4 ${R}_c4f64 --precision f64 --steps 300 --warmup 30 > gpurun_out/prof_${R}_c4f64.log 2>&1; rc=$?; echo "c4f64 rc=$rc"; cd $ROOT
+  if [ $rc -ge 124 ]; then exit $rc; fi
+  MVRL_PROFILE_PMC=0 bash tools/profile_round.sh c4in ${R}_c4in > gpurun_out/prof_${R}_c4in.log 2>&1; echo "c4in rc=$?"; cd $ROOT
   MVRL_PROFILE_PMC=0 bash tools/profile_round.sh c4 ${R}_c4zoh --control-mode zoh > gpurun_out/prof_${R}_c4zoh.log 2>&1; echo "c4zoh rc=$?"; cd $ROOT
   MVRL_PROFILE_PMC=0 bash tools/profile_round.sh c4 ${R}_c4gen --flavour generic --specialize > gpurun_out/prof_${R}_c4gen.log 2>&1; echo "c4gen rc=$?"; cd $ROOT
   du -sh gpurun_out | tail -1 ;;
@@ -26,6 +29,8 @@ summarize)
   python tools/summarize_counters.py ${R}_c2 c2 rov3_step_kernel 65536 84 165 > /dev/null
   python tools/summarize_counters.py ${R}_auv auv auv_step_kernel 1048576 292 393 > /dev/null
   python tools/summarize_counters.py ${R}_auv4m auv_4194304 auv_step_kernel 4194304 292 393 > /dev/null
+  python tools/summarize_counters.py ${R}_c4f64 c4_f64 rov6_step_kernel 1048576 432 730 > /dev/null
+  python tools/summarize_counters.py ${R}_c4in c4_in_table rov6_step_kernel 1048576 216 341 > /dev/null
   python tools/summarize_counters.py ${R}_c4zoh c4_zoh rov6_step_kernel 1048576 216 365 > /dev/null
   python tools/summarize_counters.py ${R}_c4gen c4_generic_specialised rov6_step_kernel 1048576 216 365 > /dev/null
   python - $R <<'PY'

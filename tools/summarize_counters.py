@@ -104,6 +104,11 @@ def main():
         if "SQ_INSTS_VALU_FMA_F32" in c:
             v["flops_per_env_step"] = (2 * c["SQ_INSTS_VALU_FMA_F32"] + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c.get("SQ_INSTS_VALU_ADD_F32", 0)
                                        + c.get("SQ_INSTS_VALU_TRANS_F32", 0)) / waves
+        if c.get("SQ_INSTS_VALU_FMA_F64"):
+            v["fp64_instr_per_env_step"] = {k_[len("SQ_INSTS_VALU_"):].lower(): c[k_] / waves for k_ in
+                                            ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64") if k_ in c}
+            v["flops_per_env_step"] = (2 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0)
+                                       + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) / waves
         if "SQ_WAVE_CYCLES" in c:
             v["wave_cycles_per_wave"] = 4.0 * c["SQ_WAVE_CYCLES"] / waves
             v["valu_active_cycles_per_wave"] = 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0) / waves
