@@ -327,7 +327,8 @@ int mvrl_derivs_cur_f64(mvrl_handle* h, int64_t n, const double* t, const double
  * them; the ONE exchange of the path, returning (observation, reward, done) to the root device, is a grouped ncclSend / ncclRecv
  * over RCCL / xGMI (librccl is dlopen-ed at group creation: the library itself loads without it).  A group of one device, one with
  * a repeated device (RCCL refuses duplicates: rehearsal on a 1-GPU box) or MVRL_GROUP_TRANSPORT=copy moves the messages with
- * device-to-device / peer copies instead.  fp32 handles only (the message is an fp32 format).  Not re-entrant: one host thread
+ * device-to-device / peer copies instead; MVRL_GROUP_TRANSPORT=rccl makes even a one-device group go through RCCL (a one-rank
+ * communicator sending to itself).  fp32 handles only (the message is an fp32 format).  Not re-entrant: one host thread
  * at a time per group.
  * Message per shard (the step kernel writes its outputs straight into it; = distributed.OutputGather's format):
  *   obs[cmax, obs_dim] f32 | reward[cmax] f32 (AuvEnv only: the rigid-body reward is identically 0, 6DoF.py:575) | done[cmax] u8,

@@ -213,8 +213,10 @@ int mvrl_group_create(const mvrl_config* cfg, const int32_t* devices, int32_t n_
     g->sh.resize(n_devices);
     g->first.resize(n_devices); g->count.resize(n_devices);
     const char* tr = getenv("MVRL_GROUP_TRANSPORT");
-    const bool want_copy = tr && !strcmp(tr, "copy");
-    g->use_rccl = n_devices > 1 && !dup && !want_copy;
+    const bool want_copy = tr && !strcmp(tr, "copy"), want_rccl = tr && !strcmp(tr, "rccl");
+    // RCCL needs distinct devices; a one-device group uses it only on request (MVRL_GROUP_TRANSPORT=rccl: a one-rank communicator
+    // sending to itself - the same calls, datatypes and stream protocol as the 8-GPU gather, runnable on a 1-GPU box)
+    g->use_rccl = !dup && !want_copy && (n_devices > 1 || want_rccl);
 #define G_CREATE_TRY(code_, msg_) do { const int c__ = (code_); const std::string m__ = (msg_); mvrl_group_destroy(g); return gfail(nullptr, c__, m__); } while (0)
     for (int i = 0; i < n_devices; i++) {
         mvrl_group_shard_range(cfg->n_envs, i, n_devices, &g->first[i], &g->count[i]);

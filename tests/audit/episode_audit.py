@@ -39,11 +39,12 @@ def main():
     n_sub = int(os.environ.get("MVRL_AUDIT_NSUB", "4"))                      # other parametrisations of the same audit
     mode = P.CTRL_ZOH if os.environ.get("MVRL_AUDIT_ZOH") else P.CTRL_FAITHFUL
     kw = dict(n_substeps=n_sub, control_mode=mode)
+    prec = os.environ.get("MVRL_AUDIT_PRECISION", "f32")                     # f64: the exactness mode's column of the same audit
     dof = 3 if which == "c2" else 6
     use_flow = which == "c4"
     npos = 3 if dof == 6 else 2
     model = "rov6" if dof == 6 else "rov3"
-    h = _lib.Handle(P.make_config(model, n, auto_reset=False, max_steps=10 ** 9, use_flow=use_flow, seed=12345, **kw))
+    h = _lib.Handle(P.make_config(model, n, auto_reset=False, max_steps=10 ** 9, use_flow=use_flow, seed=12345, precision=prec, **kw))
     ft = None
     if use_flow:
         flow = ReconstructedFlow.synthetic(n_modes=8, n_time=2000)
@@ -57,6 +58,8 @@ def main():
     path = st[5 * dof:5 * dof + 2 * npos].T
     init = np.concatenate([path, sp[:, npos:]], axis=1).astype(np.float64)
     toff = st[-2].copy()
+    if prec == "f64":
+        return main_f64(which, h, n, steps, dof, init, toff, ft, kw)
     ref = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft, **kw)
     low = orc.OracleRovEnv(dof, n, "f32", max_steps=10 ** 9, flow=ft, **kw)
     flo = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft, **kw)
@@ -122,6 +125,26 @@ def main():
     print(f"# per step {100 * a_gpu.near_share_per_step():.3f} % of all envs are within the fp32 bounds of a discontinuity; an env that jumped never comes back "
           f"(the closed loop is chaotic under random actions), so the share beyond 1e-5 can only grow with episode length")
     print(f"# jump threshold {SMOOTH_TOL:g}; bounds {a_gpu.bounds.tolist()}")
+    h.close()
+
+
+def main_f64(which, h, n, steps, dof, init, toff, ft, kw):
+    """precision = f64 (the mode that follows the reference for whole episodes): worst / median error and the count beyond 1e-5."""
+    ref = orc.OracleRovEnv(dof, n, "f64", max_steps=10 ** 9, flow=ft, **kw)
+    ref.reset(init, toffset=toff)
+    ang = [3, 4, 5] if dof == 6 else [2]
+    rng = np.random.default_rng(2024)
+    worst = np.zeros(n)
+    print(f"# whole-episode audit {which}, precision f64: {h.variant}, {n} envs x {steps} steps vs the fp64 oracle")
+    print("# step | envs beyond 1e-5 | worst env so far | median of the per-env worst | 99.99 % quantile")
+    t0 = time.time()
+    for s in range(steps):
+        a = rng.uniform(-1, 1, (n, dof)).astype(np.float32).astype(np.float64)
+        ref.step(a)
+        h.step(a, copy=False)
+        worst = np.maximum(worst, circ_err(h.get_state()[:2 * dof].T, ref.y, ang).max(axis=1))
+        if (s + 1) in CHECKPOINTS or s + 1 == steps:
+            print(f"{s + 1:4d} | {int((worst > 1e-5).sum()):6d} | {worst.max():.2e} | {np.median(worst):.2e} | {np.quantile(worst, 0.9999):.2e}   [{time.time() - t0:.0f} s]", flush=True)
     h.close()
 
 

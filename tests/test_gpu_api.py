@@ -700,6 +700,34 @@ def test_group_c_example_runs_on_shards_of_one_card(tmp_path):
 
 
 # ---- several devices behind one object (mvrl_group_*) ------------------------------------------------------------------------
+def test_device_group_through_rccl_on_one_device(tmp_path):
+    """The RCCL transport itself - dlopen of librccl, ncclCommInitAll, grouped ncclSend / ncclRecv on the communication stream, the
+    event protocol around it - on the one device this box has: a one-rank communicator sending to itself (MVRL_GROUP_TRANSPORT=rccl).
+    Run in a child process under a time limit: a collective that stalls must not take the test session with it."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch\n"
+        "from marinevehiclereinforcementlearning_amd import _lib, params as P\n"
+        "from marinevehiclereinforcementlearning_amd.group import DeviceGroup\n"
+        "n = 4096 + 13\n"
+        "g = DeviceGroup(P.make_config('rov6', n, use_flow=False, seed=3, max_steps=5), [0])\n"
+        "assert g.transport == 'rccl', g.transport\n"
+        "h = _lib.Handle(P.make_config('rov6', n, use_flow=False, seed=3, max_steps=5))\n"
+        "o0 = h.reset(); g.reset(); g.gather_dev()\n"
+        "assert np.array_equal(g.download()[0], o0)\n"
+        "a = torch.rand((n, 6), device='cuda:0') * 2 - 1; torch.cuda.synchronize()\n"
+        "for s in range(12):\n"
+        "    g.scatter_actions_dev(a.data_ptr()); g.step_dev(); g.gather_dev()\n"
+        "    o, r, d = g.download(); ho, hr, hd = h.step(a.cpu().numpy())\n"
+        "    assert np.array_equal(o, ho) and np.array_equal(d, hd), s\n"
+        "g.close(); h.close(); print('rccl one-rank group ok')\n")
+    env = dict(os.environ, MVRL_GROUP_TRANSPORT="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "rccl one-rank group ok" in r.stdout, (r.stdout[-300:], r.stderr[-800:])
+
+
 @pytest.mark.parametrize("model,devices", [("rov6", [0]), ("rov6", [0, 0]), ("auv", [0, 0, 0]), ("rov3", [0, 0])])
 def test_device_group_equals_the_unsharded_batch(model, devices):
     """A group steps its shards (one launch per device, no host sync), gathers their messages to the root and hands out the global

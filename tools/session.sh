@@ -9,12 +9,16 @@
 PART=$1; R=${2:-r04}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"; ROOT=$PWD
 case "$PART" in
-profiles)
+profiles|profiles_a|profiles_b)
+  # one gpurun call is limited to 20 minutes: part a = the four BASELINE-sized workloads, part b = the rest
+  if [ "$PART" != "profiles_b" ]; then
   for spec in "c4 ${R}_c4" "c3 ${R}_c3" "c2 ${R}_c2" "auv ${R}_auv"; do
     set -- $spec
     bash tools/profile_round.sh $1 $2 > gpurun_out/prof_$2.log 2>&1; rc=$?; echo "$2 rc=$rc"; cd $ROOT
     if [ $rc -ge 124 ]; then exit $rc; fi
   done
+  fi
+  if [ "$PART" != "profiles_a" ]; then
   bash tools/profile_round.sh auv ${R}_auv4m --envs-per-gpu 4194304 > gpurun_out/prof_${R}_auv4m.log 2>&1; rc=$?; echo "auv4m rc=$rc"; cd $ROOT
   if [ $rc -ge 124 ]; then exit $rc; fi
   bash tools/profile_round.sh c4 ${R}_c4f64 --precision f64 --steps 300 --warmup 30 > gpurun_out/prof_${R}_c4f64.log 2>&1; rc=$?; echo "c4f64 rc=$rc"; cd $ROOT
@@ -22,6 +26,7 @@ profiles)
   MVRL_PROFILE_PMC=0 bash tools/profile_round.sh c4in ${R}_c4in > gpurun_out/prof_${R}_c4in.log 2>&1; echo "c4in rc=$?"; cd $ROOT
   MVRL_PROFILE_PMC=0 bash tools/profile_round.sh c4 ${R}_c4zoh --control-mode zoh > gpurun_out/prof_${R}_c4zoh.log 2>&1; echo "c4zoh rc=$?"; cd $ROOT
   MVRL_PROFILE_PMC=0 bash tools/profile_round.sh c4 ${R}_c4gen --flavour generic --specialize > gpurun_out/prof_${R}_c4gen.log 2>&1; echo "c4gen rc=$?"; cd $ROOT
+  fi
   du -sh gpurun_out | tail -1 ;;
 summarize)
   python tools/summarize_counters.py ${R}_c4 c4 rov6_step_kernel 1048576 216 365 > /dev/null
