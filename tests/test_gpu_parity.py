@@ -671,14 +671,15 @@ def test_masked_reset_and_state_roundtrip():
 
 
 # ---- whole episodes ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("which,ceiling", [("c4", 0.52), ("c3", 0.05), ("c2", 0.006)])
+@pytest.mark.parametrize("which,ceiling", [("c4", 0.49), ("c3", 0.05), ("c2", 0.006)])
 def test_whole_episode_parity_not_below_the_fp32_storage_floor(oracle_mod, which, ceiling):
     """A full 250-step episode (6DoF.py:569-571) of the bench's population, 4096 envs, against the fp64 oracle: the share of envs that
     have left 1e-5 by the end.  Under random actions the loop is chaotic, so that share is large by then - the statement
     tested is RELATIVE: the kernel must lose no more envs than the same fp64 oracle whose state words are rounded to fp32 once per env
     step (what any implementation that keeps plain fp32 state between steps could reach at best; the binary angles are why the kernel
-    does better), and stay under a ceiling 20 % above what 65 536 envs measured (profiles/r04_error_audit_episode.txt: 42.8 / 2.78 /
-    0.18 %; before the binary angles 72.7 / 7.1 / 0.37 %)."""
+    does better), and stay under a ceiling 20 % above what 65 536 envs measured (profiles/r05_error_audit_episode.txt: 40.8 / 2.78 /
+    0.18 %; round 4, fp32 turbulence sample time: 42.8 %; before the binary angles 72.7 / 7.1 / 0.37 %).  The mode that does follow the
+    reference for whole episodes is precision = f64 (tests/test_gpu_f64.py::test_f64_whole_episode_follows_the_reference)."""
     from marinevehiclereinforcementlearning_amd.flow import ReconstructedFlow
     n, steps = 4096, 250
     dof = 3 if which == "c2" else 6

@@ -82,5 +82,16 @@ evidence)
     timeout -k 10 400 python tests/audit/err_quantiles.py 262144 25 8 0 6 2>&1 | grep -v amdgpu.ids
   } > gpurun_out/${R}_error_audit_25.txt 2>&1
   grep -E "lib=|beyond 1e-5|control" gpurun_out/${R}_error_audit_25.txt ;;
-*) echo "usage: tools/session.sh profiles|summarize|table|driver_runs|evidence <round>"; exit 2 ;;
+audits)
+  # whole-episode parity audits (65 536 envs x 250 steps each against the fp64 oracle; tests/audit/episode_audit.py) -> gpurun_out/<round>_audit_*.txt
+  export MVRL_CPU_THREADS=16 OMP_NUM_THREADS=16
+  bash tools/gpu_steps.sh \
+    "${R}_audit_c4|400|python tests/audit/episode_audit.py c4 65536 250" \
+    "${R}_audit_c4_t32|400|MVRL_LIB=variants_build/libmvrl_flowt32.so python tests/audit/episode_audit.py c4 65536 250" \
+    "${R}_audit_c3|400|python tests/audit/episode_audit.py c3 65536 250" \
+    "${R}_audit_c2|400|python tests/audit/episode_audit.py c2 65536 250" \
+    "${R}_audit_c4_f64|400|MVRL_AUDIT_PRECISION=f64 python tests/audit/episode_audit.py c4 65536 250" \
+    "${R}_audit_c3_f64|400|MVRL_AUDIT_PRECISION=f64 python tests/audit/episode_audit.py c3 65536 250" \
+    "${R}_audit_c2_f64|400|MVRL_AUDIT_PRECISION=f64 python tests/audit/episode_audit.py c2 65536 250" ;;
+*) echo "usage: tools/session.sh profiles_a|profiles_b|summarize|table|driver_runs|evidence|audits <round>"; exit 2 ;;
 esac
