@@ -188,3 +188,48 @@ def test_f64_whole_episode_follows_the_reference(oracle_mod, which):
     print(f"f64 {which}: worst env {worst.max():.1e}, median {np.median(worst):.1e}, beyond 1e-5: {int((worst > 1e-5).sum())} of {n} after {steps} steps")
     assert (worst > 1e-5).sum() == 0 and worst.max() < 1e-6, worst.max()
     h.close()
+
+
+@pytest.mark.parametrize("seed", [2024, 3, 7, 11, 19])
+def test_f64_config_sweep_has_no_budget(oracle_mod, seed):
+    """The configuration sweep of tests/test_gpu_parity.py::test_config_fuzz_vs_oracle (ragged batch sizes, odd sub-step counts, other dt,
+    fixed set-point x turbulence x controller placement x kernel flavour) through precision = f64: the SAME kernel text, and NO outlier
+    accounting, drift budget or second yardstick - every env of every case within 1e-8 of the fp64 oracle.  What the fp32 sweep budgets
+    for is therefore rounding, not logic: any branch, flavour or launch geometry the sweep reaches computes the reference's algorithm."""
+    from oracle import flow_ref
+    from .parity_util import fuzz_cases
+    from .conftest import GOLDEN
+    modes, coeffs = synthetic_spod(4, 64)
+    ltm = np.load(os.path.join(GOLDEN, "ltm.npy"))
+    base = flow_ref.reconstruct(modes, coeffs, ltm)
+    coords = np.load(os.path.join(GOLDEN, "turbulence_coords.npy"))
+    bdx, bdy = flow_ref.grid_spacing(coords)
+    fd, fdx, fdy, fdt = flow_ref.scale(base, bdx, bdy, BASE_DT, 11., 1., 2.)
+    uv = np.ascontiguousarray(fd[..., :2]).astype(np.float32).astype(np.float64)
+    variants, worst_all = set(), 0.0
+    for c in fuzz_cases(seed):
+        dof, n, fixed, use_flow, kw = c["dof"], c["n"], c["fixed"], c["use_flow"], c["kw"]
+        h = _lib.Handle(P.make_config("rov6" if dof == 6 else "rov3", n, dt=c["dt"], n_substeps=c["n_sub"], control_mode=c["mode"],
+                                      fixed_setpoint=fixed, auto_reset=False, max_steps=10 ** 9, use_flow=use_flow, precision="f64", **kw))
+        if use_flow:
+            h.set_flow(uv, fdt, fdx, fdy)
+        h.reset(init=c["init"].astype(np.float64))
+        st = h.get_state()
+        st[-2] = c["toff"]
+        h.set_state(st)
+        env = oracle_mod.OracleRovEnv(dof, n, "f64", dt=c["dt"], n_substeps=c["n_sub"], control_mode=c["mode"], fixed_setpoint=fixed,
+                                      max_steps=10 ** 9, flow=oracle_mod.FlowTable(uv, fdt, fdx, fdy) if use_flow else None, **kw)
+        env.reset(c["init"].astype(np.float64), toffset=c["toff"])
+        worst = 0.0
+        for k in range(c["steps"]):
+            a = c["actions"][k].astype(np.float64)
+            o_ref, _, _ = env.step(a)
+            o_gpu, _, _ = h.step(None if fixed else a)
+            worst = max(worst, float(circ_err(h.get_state()[: 2 * dof].T, env.y, [3, 4, 5] if dof == 6 else [2]).max()),
+                        float(np.abs(o_gpu - o_ref).max()))
+        variants.add(h.variant)
+        worst_all = max(worst_all, worst)
+        assert worst < 1e-8, (seed, c["case"], h.variant, worst)
+        h.close()
+    print(f"f64 sweep seed {seed}: worst {worst_all:.1e} over 24 cases, kernels {sorted(variants)}")
+    assert len(variants) >= 5
