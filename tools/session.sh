@@ -71,6 +71,8 @@ evidence)
     echo "## c4, two chains"; bash tools/clock_watch.sh "" 12000
     echo "## c4, one launch per step"; bash tools/clock_watch.sh "" 12000 --chains 1 --launch single
     echo "## c3 at 1 048 576 envs (no turbulence)"; bash tools/clock_watch.sh "" 12000 --workload c3 --envs-per-gpu 1048576
+    echo "## c4, precision f64, two chains"; bash tools/clock_watch.sh "" 5000 --precision f64
+    echo "## auv at 4 194 304 envs (HBM-bound)"; bash tools/clock_watch.sh "" 4000 --workload auv --envs-per-gpu 4194304
   } > gpurun_out/${R}_power_clock.txt 2>&1
   grep -v "^$" gpurun_out/${R}_power_clock.txt | tail -24
   export MVRL_CPU_THREADS=16 OMP_NUM_THREADS=16
@@ -81,7 +83,14 @@ evidence)
     timeout -k 10 400 python tests/audit/err_quantiles.py 262144 40 4 1 6 2>&1 | grep -v amdgpu.ids
     timeout -k 10 400 python tests/audit/err_quantiles.py 262144 25 8 0 6 2>&1 | grep -v amdgpu.ids
   } > gpurun_out/${R}_error_audit_25.txt 2>&1
-  grep -E "lib=|beyond 1e-5|control" gpurun_out/${R}_error_audit_25.txt ;;
+  grep -E "lib=|beyond 1e-5|control" gpurun_out/${R}_error_audit_25.txt
+  timeout -k 10 300 python tools/soak.py 100000 > gpurun_out/${R}_soak.txt 2>&1; tail -2 gpurun_out/${R}_soak.txt ;;
+audit_f64_1m)
+  # the fp64 mode at BASELINE configs[3]'s full size for a whole episode: 1 048 576 envs x 250 steps against the fp64 oracle (the oracle is
+  # the slow side: ~6 min on the box's 16 cores)
+  export MVRL_CPU_THREADS=16 OMP_NUM_THREADS=16
+  MVRL_AUDIT_PRECISION=f64 timeout -k 10 900 python tests/audit/episode_audit.py c4 1048576 250 > gpurun_out/${R}_audit_c4_f64_1m.txt 2>&1
+  tail -8 gpurun_out/${R}_audit_c4_f64_1m.txt ;;
 audits)
   # whole-episode parity audits (65 536 envs x 250 steps each against the fp64 oracle; tests/audit/episode_audit.py) -> gpurun_out/<round>_audit_*.txt
   export MVRL_CPU_THREADS=16 OMP_NUM_THREADS=16
