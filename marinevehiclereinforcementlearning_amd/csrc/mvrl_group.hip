@@ -230,8 +230,12 @@ int mvrl_group_create(const mvrl_config* cfg, const int32_t* devices, int32_t n_
             e = hipMalloc(&s.msg[b], (size_t)g->lay.msg_bytes);
             if (e == hipSuccess) e = hipMemset(s.msg[b], 0, (size_t)g->lay.msg_bytes);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_step[b], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_sent[b], hipEventDisableTiming);
         }
+        // "message b has left its buffer": recorded on the shard's own communication stream under RCCL, on the ROOT's under the copy
+        // transport (the root pulls) - an event is recorded on a stream of the device it was created on, waited for from any device
+        if (e == hipSuccess && !g->use_rccl) e = hipSetDevice(devices[root]);
+        for (int b = 0; b < 2 && e == hipSuccess; b++) e = hipEventCreateWithFlags(&s.ev_sent[b], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipSetDevice(devices[i]);
         if (e == hipSuccess && !reward_plane) e = hipMalloc(&s.rew_scratch, (size_t)g->lay.cmax * 4);
         if (e == hipSuccess) e = hipMalloc(&s.actions, (size_t)g->count[i] * act * 4);
         if (e == hipSuccess) e = hipMemset(s.actions, 0, (size_t)g->count[i] * act * 4);

@@ -183,3 +183,115 @@ class DeviceGroup:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+class GroupVecEnv:
+    """SB3 `VecEnv` calling convention over a `DeviceGroup`: ONE Python process, the node's GPUs, the whole batch in global env order -
+    what `SubprocVecEnv([make_env(i) for i in range(nProc)])` (tag/main_00_sbl.py:145) is to its caller, without the processes.
+
+        venv = GroupVecEnv("rov6", 8 * 1048576, devices=range(8), flow=flow)
+        obs = venv.reset()
+        obs, rewards, dones, infos = venv.step(actions)        # numpy [N, ...] in, numpy out; auto-reset + terminal_observation
+
+    Per step: the action batch is uploaded to the root device and scattered to the shards, every device launches its shard's step,
+    the shards' (obs, reward, done) messages are gathered to the root (grouped RCCL send / recv; device-to-device copies for a single
+    or repeated device) and downloaded in one piece per plane.  `infos` are lean (a list-like that builds a dict on access)."""
+
+    def __init__(self, model, num_envs, devices, *, seed=0, dt=None, maxSteps=250, n_substeps=4, control_mode="faithful", flow=None,
+                 noiseMagCoeffs=0.0, noiseMagActuation=0.0, stopOnBoundsExceeded=True, report_truncation=False, root=0):
+        from .spaces import unit_box
+        cyl = model == "auv_cyl"
+        if cyl:
+            model, maxSteps = "auv", (1200 if maxSteps == 250 else maxSteps)
+        self.model = P.MODEL_NAMES[model] if isinstance(model, str) else int(model)
+        self.num_envs = int(num_envs)
+        act, obs = P.MODEL_DIMS[self.model][:2]
+        self.action_space, self.observation_space = unit_box(act), unit_box(obs)
+        self.report_truncation = bool(report_truncation)
+        if self.model == P.MODEL_AUV and flow is None:
+            raise ValueError("AuvEnv needs a turbulence field (flow=ReconstructedFlow(...)): verySimpleAuv.py:102-104")
+        kw = {"auv": P.auv_params(noiseMagCoeffs, noiseMagActuation, stopOnBoundsExceeded, cyl=cyl)} if self.model == P.MODEL_AUV else {}
+        cm = {"faithful": P.CTRL_FAITHFUL, "zoh": P.CTRL_ZOH}[control_mode] if isinstance(control_mode, str) else control_mode
+        self.cfg = P.make_config(self.model, self.num_envs, dt=dt, n_substeps=n_substeps, max_steps=maxSteps, control_mode=cm,
+                                 auto_reset=True, seed=seed or 0, use_flow=flow is not None, **kw)
+        self.group = DeviceGroup(self.cfg, list(devices), root=root)
+        if flow is not None:
+            if self.model == P.MODEL_AUV:
+                flow.scale(11., 1.0, 2.0, translate=(-1.65, -1.1))      # verySimpleAuv.py:104
+            self.group.set_flow(flow.table_uv(), flow.dt, flow.dx, flow.dy)
+        self._shards = [self.group.shard(i) for i in range(len(self.group.devices))]
+        self._root = self._shards[self.group.root]
+        self._act_ptr = self._root.dev_alloc(self.num_envs * act * 4)
+        self._pending = False
+
+    def reset(self):
+        self.group.reset()
+        self.group.gather_dev()
+        return self.group.download()[0]
+
+    def step_async(self, actions):
+        a = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.num_envs, self.action_space.shape[0]))
+        self._root.dev_upload(self._act_ptr, a)                 # synchronous: complete before the scatter is enqueued
+        self.group.scatter_actions_dev(self._act_ptr)
+        self.group.step_dev()
+        self.group.gather_dev()
+        self._pending = True
+
+    def step_wait(self):
+        obs, rew, bits = self.group.download()
+        self._pending = False
+        dones = bits != 0
+        infos = [{} for _ in range(self.num_envs)] if self.num_envs <= 65536 else _LazyInfos(self.num_envs)
+        idx = np.nonzero(dones)[0]
+        if len(idx):
+            term = np.concatenate([s.terminal_obs() for s in self._shards], axis=0)
+            for i in idx:
+                infos[i] = {"terminal_observation": term[i].copy()}
+                if self.report_truncation:
+                    infos[i]["TimeLimit.truncated"] = bool(bits[i] & 2)
+        return obs, rew, dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def get_state(self, raw=True):
+        """The shards' state planes side by side = the planes of the unsharded batch (raw: the C ABI's bit patterns)."""
+        return np.concatenate([s.get_state(raw=raw) for s in self._shards], axis=1)
+
+    def close(self):
+        if getattr(self, "group", None) is not None:
+            try:
+                self._root.dev_free(self._act_ptr)
+            except Exception:  # noqa: BLE001
+                pass
+            self._shards = []
+            self.group.close()
+            self.group = None
+
+    def seed(self, seed=None):
+        return [None] * self.num_envs
+
+    def render(self, mode="human"):
+        return None
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.num_envs
+
+    def get_attr(self, attr_name, indices=None):
+        return [getattr(self, attr_name)] * self.num_envs
+
+
+class _LazyInfos(dict):
+    """infos of a very large batch: a mapping index -> dict that answers {} for envs that did not finish (a million empty dicts
+    per step cost more than the step)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self._n = n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        return dict.get(self, i, {})

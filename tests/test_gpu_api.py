@@ -782,3 +782,26 @@ def test_device_group_equals_the_unsharded_batch(model, devices):
     assert np.array_equal(o1, h.step(a)[0]) and np.array_equal(o2, h.step(a)[0])
     g.close()
     h.close()
+
+
+def test_group_vecenv_is_the_marinevecenv_of_the_whole_batch():
+    """group.GroupVecEnv - SB3's VecEnv calling convention over a DeviceGroup, one Python process for all GPUs - against
+    MarineVecEnv on the whole batch: same observations, rewards, dones, terminal observations and truncation flags, step by step
+    (three shards on the box's one card; ragged; auto-resets)."""
+    from marinevehiclereinforcementlearning_amd.group import GroupVecEnv
+    n = 64 * 3 + 11
+    kw = dict(seed=5, maxSteps=4, report_truncation=True)
+    g = GroupVecEnv("rov6", n, [0, 0, 0], **kw)
+    v = MarineVecEnv("rov6", n, **kw)
+    assert np.array_equal(g.reset(), v.reset())
+    rng = np.random.default_rng(3)
+    for s in range(10):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        go, gr, gd, gi = g.step(a)
+        vo, vr, vd, vi = v.step(a)
+        assert np.array_equal(go, vo) and np.array_equal(gr, vr) and np.array_equal(gd, vd), s
+        for i in np.nonzero(vd)[0]:
+            assert np.array_equal(gi[i]["terminal_observation"], vi[i]["terminal_observation"])
+            assert gi[i]["TimeLimit.truncated"] == vi[i]["TimeLimit.truncated"]
+    assert np.array_equal(g.get_state().view(np.uint32), v.get_state(raw=True).view(np.uint32))
+    g.close(); v.close()

@@ -104,7 +104,7 @@ def main():
         if "SQ_INSTS_VALU_FMA_F32" in c:
             v["flops_per_env_step"] = (2 * c["SQ_INSTS_VALU_FMA_F32"] + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c.get("SQ_INSTS_VALU_ADD_F32", 0)
                                        + c.get("SQ_INSTS_VALU_TRANS_F32", 0)) / waves
-        if c.get("SQ_INSTS_VALU_FMA_F64"):
+        if c.get("SQ_INSTS_VALU_FMA_F64", 0) > c.get("SQ_INSTS_VALU_FMA_F32", 0):   # an fp64 kernel (the fp32 ones form the turbulence sample time in fp64: a handful)
             v["fp64_instr_per_env_step"] = {k_[len("SQ_INSTS_VALU_"):].lower(): c[k_] / waves for k_ in
                                             ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64") if k_ in c}
             v["flops_per_env_step"] = (2 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0)
