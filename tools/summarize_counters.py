@@ -117,6 +117,21 @@ def main():
         if "GRBM_GUI_ACTIVE" in c and dur_ns:
             v["effective_clock_GHz_under_profiler"] = c["GRBM_GUI_ACTIVE"] / 8.0 / dur_ns
             v["kernel_us_under_profiler"] = dur_ns / 1e3
+        if wl == "c2" and "wave_cycles_per_wave" in v:
+            # VERDICT r4 "next 5" (two lanes per env, two thrusters each): what the counters say about it.  C2 is ONE wave per SIMD; a
+            # second wave can only use the cycles the first leaves idle, and splitting an env over two lanes makes BOTH run the per-env
+            # part of every RK stage (PID, Coriolis / damping / M^-1, kinematics, stage rotation, RK bookkeeping: ~148 of ~220
+            # instructions per stage; only allocation rows, saturation / dead-band and jet drag - ~72 - are per thruster)
+            busy, life = v["valu_active_cycles_per_wave"], v["wave_cycles_per_wave"]
+            share = (220.0 - 36.0 + 6.0) / 220.0        # per lane: half of the per-thruster part saved, 6 instructions of exchange added
+            v["two_lanes_per_env_estimate"] = {
+                "waves_per_simd_now": 1, "valu_busy_share_of_the_wave_life": busy / life,
+                "instructions_per_lane_relative": share, "valu_cycles_of_two_waves_relative_to_the_wave_life_now": 2.0 * share * busy / life,
+                "note": "the lone wave keeps its SIMD's VALU busy for %.0f %% of its life (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES); two lanes per env would "
+                        "put two waves on the SIMD, each executing %.0f %% of the instructions: by the measured issue rates (profiles/r05_valu_ops.txt: "
+                        "2.24 ns per instruction for one wave per SIMD, 1.24 ns for two) 2 x %.2f x 1.24 = %.2f ns of issue per instruction of the present "
+                        "kernel against 2.24 now - a 4 %% shorter kernel; not built (DESIGN.md section 5)" % (
+                            100.0 * busy / life, 100.0 * share, share, 2.0 * share * 1.24)}
         ent["valu"] = v
     path = os.path.join(PROF, f"{tag.split('_')[0]}_counters.json")
     data = json.load(open(path)) if os.path.exists(path) else {"workloads": {}}
