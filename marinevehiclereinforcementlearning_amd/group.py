@@ -198,7 +198,8 @@ class GroupVecEnv:
     or repeated device) and downloaded in one piece per plane.  `infos` are lean (a list-like that builds a dict on access)."""
 
     def __init__(self, model, num_envs, devices, *, seed=0, dt=None, maxSteps=250, n_substeps=4, control_mode="faithful", flow=None,
-                 noiseMagCoeffs=0.0, noiseMagActuation=0.0, stopOnBoundsExceeded=True, report_truncation=False, root=0):
+                 currentVelScale=1.0, currentTurbScale=2.0, noiseMagCoeffs=0.0, noiseMagActuation=0.0, stopOnBoundsExceeded=True,
+                 report_truncation=False, root=0):
         from .spaces import unit_box
         cyl = model == "auv_cyl"
         if cyl:
@@ -217,7 +218,7 @@ class GroupVecEnv:
         self.group = DeviceGroup(self.cfg, list(devices), root=root)
         if flow is not None:
             if self.model == P.MODEL_AUV:
-                flow.scale(11., 1.0, 2.0, translate=(-1.65, -1.1))      # verySimpleAuv.py:104
+                flow.scale(11., currentVelScale, currentTurbScale, translate=(-1.65, -1.1))      # verySimpleAuv.py:104
             self.group.set_flow(flow.table_uv(), flow.dt, flow.dx, flow.dy)
         self._shards = [self.group.shard(i) for i in range(len(self.group.devices))]
         self._root = self._shards[self.group.root]
