@@ -255,3 +255,16 @@ def fuzz_cases(seed, n_cases=24):
         toff = (rng.random(n) * 2.0).astype(np.float32)
         yield dict(case=case, dof=dof, n=n, dt=dt, n_sub=n_sub, mode=mode, fixed=fixed, use_flow=use_flow, over=over, kw=kw, steps=steps,
                    init=init, actions=actions, toff=toff)
+
+
+def uniform_current_table(cur_seq):
+    """A spatially uniform (u, v) table that serves the per-step current sequence of golden G23 to the step kernels / the oracle: slice
+    k + 1 holds the current of env step k (the composition samples at time = (k + 1) dt, after the increment: verySimpleAuv.py:266-267,
+    :291), so with the table's time spacing = the env's dt and a zero time offset every sample falls on a slice.  Returns
+    (table [n_steps + 2, 2, 2, 2] float64, dt_table-agnostic spacing dx = dy = 1)."""
+    n = len(cur_seq)
+    t = np.zeros((n + 2, 2, 2, 2))
+    t[1:n + 1] = np.asarray(cur_seq, np.float64)[:, None, None, :]
+    t[0] = t[1]
+    t[n + 1] = t[n]
+    return t

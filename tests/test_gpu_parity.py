@@ -95,6 +95,52 @@ def test_reference_rk4_trajectories(oracle_mod, name, dof, n_sub, mode):
     h.close()
 
 
+@pytest.mark.parametrize("dof", [3, 6])
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_reference_rk4_trajectories_with_current(oracle_mod, dof, precision):
+    """G23 through the step KERNELS with turbulence on (`FLOW` instances): the reference's derivs executed with a current that changes
+    every env step (the hooks of G21 / G22), served to the kernel by its own table lookup - a spatially uniform table whose slice k + 1
+    is the current of step k, time spacing = the env's dt, zero offset - so lookup time, hold-over-the-step and the composition's
+    right-hand side are pinned together against reference-executed trajectories.  fp64: 1e-9 on every env; fp32: 1e-5 with the usual
+    accounting of envs that pass a discontinuity (the oracle, which reproduces G23 to 1e-9, reports the distances)."""
+    from .parity_util import uniform_current_table
+    g = golden(f"g23_rk4_{dof}dof_current.npz")
+    n_env, n_steps = g["actions"].shape[:2]
+    dt = float(g["dt"])
+    tab = uniform_current_table(g["cur_seq"])
+    h = _lib.Handle(P.make_config("rov6" if dof == 6 else "rov3", n_env, dt=dt, n_substeps=int(g["n_sub"]), auto_reset=False,
+                                  max_steps=10 ** 9, use_flow=True, precision=precision))
+    h.set_flow(tab.astype(h.dtype), dt, 1.0, 1.0)
+    assert "+flow" in h.variant
+    init = rov_init(g, dof)
+    obs0 = h.reset(init=init.astype(h.dtype))            # explicit initial values: the time offset plane is 0
+    assert max_scaled_err(obs0, g["obs"][:, 0]) < (1e-12 if precision == "f64" else TOL)
+    env = oracle_mod.OracleRovEnv(dof, n_env, "f64", dt=dt, n_substeps=int(g["n_sub"]), max_steps=10 ** 9,
+                                  flow=oracle_mod.FlowTable(tab, dt, 1.0, 1.0))
+    env.reset(init.astype(np.float64), toffset=np.zeros(n_env))
+    ang = [3, 4, 5] if dof == 6 else [2]
+    audit = OutlierAudit(n_env, TOL, dof=dof)
+    worst = 0.0
+    for s in range(n_steps):
+        a = g["actions"][:, s]
+        obs, _, _ = h.step(a.astype(h.dtype))
+        env.step(a.astype(np.float64))
+        assert circ_err(env.y, g["states"][:, s + 1], ang).max() < 1e-8
+        e = circ_err(h.get_state()[: 2 * dof].T, g["states"][:, s + 1], ang).max(axis=1)
+        worst = max(worst, float(e.max()))
+        audit.update(e, env.margins)
+        on = ~audit.bad
+        if on.any():
+            assert max_scaled_err(obs[on], g["obs"][on, s + 1]) < (1e-9 if precision == "f64" else 2 * TOL), s
+    print(f"g23 dof {dof} {precision}: worst {worst:.1e}; " + audit.report())
+    if precision == "f64":
+        assert worst < 1e-9, worst
+    else:
+        audit.assert_explained(max_smooth_share=1.0 / n_env)
+        assert audit.bad.sum() <= 1, audit.report()
+    h.close()
+
+
 @pytest.mark.parametrize("dof,mode,n_sub", [(6, P.CTRL_FAITHFUL, 4), (6, P.CTRL_ZOH, 4), (3, P.CTRL_FAITHFUL, 4),
                                             (3, P.CTRL_ZOH, 4), (6, P.CTRL_FAITHFUL, 2), (6, P.CTRL_FAITHFUL, 8)])
 def test_random_batch_vs_fp64_oracle(oracle_mod, dof, mode, n_sub):

@@ -58,6 +58,28 @@ def test_rk4_harness_trajectories(oracle_mod, name, dof, n_sub, mode):
     assert err["pid"] < 1e-9, err
 
 
+@pytest.mark.parametrize("dof", [3, 6])
+def test_rk4_harness_trajectories_with_current(oracle_mod, dof):
+    """G23: the reference's derivs EXECUTED with a water current that changes every env step (hooks of G21 / G22) under the RK4
+    harness - the 3/6-DoF + turbulence composition at trajectory level.  The oracle is served the same sequence through its flow
+    lookup (a spatially uniform table whose slices are the per-step currents), so this pins sampling time, hold-over-the-step and the
+    right-hand side together."""
+    from .parity_util import uniform_current_table
+    g = golden(f"g23_rk4_{dof}dof_current.npz")
+    n_env, n_steps = g["actions"].shape[:2]
+    dt = float(g["dt"])
+    ft = oracle_mod.FlowTable(uniform_current_table(g["cur_seq"]), dt, 1.0, 1.0)
+    env = oracle_mod.OracleRovEnv(dof, n_env, "f64", dt=dt, n_substeps=int(g["n_sub"]), max_steps=10 ** 9, flow=ft)
+    npos = 3 if dof == 6 else 2
+    obs0 = env.reset(np.concatenate([g["path"].reshape(n_env, 2 * npos), g["sp0"][:, npos:]], axis=1), toffset=np.zeros(n_env))
+    worst = max_scaled_err(obs0, g["obs"][:, 0])
+    for s in range(n_steps):
+        obs, _, _ = env.step(g["actions"][:, s])
+        worst = max(worst, max_scaled_err(env.y, g["states"][:, s + 1]), max_scaled_err(obs, g["obs"][:, s + 1]),
+                    max_scaled_err(env.eold, g["eOld"][:, s]), max_scaled_err(env.eint, g["eInt"][:, s]))
+    assert worst < 1e-9, worst
+
+
 @pytest.mark.parametrize("name,dof", [("g10_envstep_6dof_random.npz", 6), ("g10_envstep_6dof_fixedsp.npz", 6),
                                       ("g10_envstep_3dof_fixedsp.npz", 3)])
 def test_envstep_rk45_trajectories(oracle_mod, name, dof):
