@@ -141,6 +141,55 @@ def test_reference_rk4_trajectories_with_current(oracle_mod, dof, precision):
     h.close()
 
 
+@pytest.mark.parametrize("dof", [3, 6])
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_fully_reference_composed_trajectories(oracle_mod, dof, precision):
+    """G24 through the step kernels: the benched kind of workload - 3/6-DoF + turbulence - composed ENTIRELY of executed reference code
+    (ReconstructedFlow.interp with AuvEnv's scaling and sampling rule feeding the vehicles' own velCurrent lines; 6-DoF hook-assisted;
+    RK4 harness, fixed set-points inside the table, 8 envs x 36 steps).  The kernel looks the current up in ITS table (re-packed
+    stencil cells, sample time in fp64), holds it over the step and resolves it per RK stage: fp64 1e-9 on every env, fp32 1e-5 with
+    the usual accounting (the oracle, which reproduces G24 to 1e-9, reports the distances to the discontinuities)."""
+    from .test_oracle_traj import composed_flow_table
+    g = golden(f"g24_composed_{dof}dof.npz")
+    n_env, n_steps = g["states"].shape[0], g["states"].shape[1] - 1
+    uv, fdt, fdx, fdy = composed_flow_table(g)
+    npos = 3 if dof == 6 else 2
+    sp = g["sp"]
+    init = np.concatenate([sp[:, :npos], sp[:, :npos], sp[:, npos:]], axis=1)
+    h = _lib.Handle(P.make_config("rov6" if dof == 6 else "rov3", n_env, dt=float(g["dt"]), n_substeps=int(g["n_sub"]), fixed_setpoint=True,
+                                  auto_reset=False, max_steps=10 ** 9, use_flow=True, precision=precision))
+    h.set_flow(uv.astype(h.dtype), fdt, fdx, fdy)
+    h.reset(init=init.astype(h.dtype))
+    st = h.get_state()
+    st[: 2 * dof] = g["start"].T
+    st[-2] = g["toff"]
+    h.set_state(st)
+    env = oracle_mod.OracleRovEnv(dof, n_env, "f64", dt=float(g["dt"]), n_substeps=int(g["n_sub"]), fixed_setpoint=True, max_steps=10 ** 9,
+                                  flow=oracle_mod.FlowTable(uv, fdt, fdx, fdy))
+    env.reset(init, toffset=g["toff"])
+    env.y[:] = g["start"]
+    ang = [3, 4, 5] if dof == 6 else [2]
+    audit = OutlierAudit(n_env, TOL, dof=dof)
+    worst = 0.0
+    for s in range(n_steps):
+        obs, _, _ = h.step(None)
+        env.step(np.zeros((n_env, dof)))
+        assert circ_err(env.y, g["states"][:, s + 1], ang).max() < 1e-8
+        e = circ_err(h.get_state()[: 2 * dof].T, g["states"][:, s + 1], ang).max(axis=1)
+        worst = max(worst, float(e.max()))
+        audit.update(e, env.margins)
+        on = ~audit.bad
+        if on.any():
+            assert max_scaled_err(obs[on], g["obs"][on, s + 1]) < (1e-9 if precision == "f64" else 2 * TOL), s
+    print(f"g24 dof {dof} {precision}: worst {worst:.1e}; " + audit.report())
+    if precision == "f64":
+        assert worst < 1e-9, worst
+    else:
+        audit.assert_explained(max_smooth_share=1.0 / n_env)
+        assert audit.bad.sum() <= 1, audit.report()
+    h.close()
+
+
 @pytest.mark.parametrize("dof,mode,n_sub", [(6, P.CTRL_FAITHFUL, 4), (6, P.CTRL_ZOH, 4), (3, P.CTRL_FAITHFUL, 4),
                                             (3, P.CTRL_ZOH, 4), (6, P.CTRL_FAITHFUL, 2), (6, P.CTRL_FAITHFUL, 8)])
 def test_random_batch_vs_fp64_oracle(oracle_mod, dof, mode, n_sub):

@@ -80,6 +80,45 @@ def test_rk4_harness_trajectories_with_current(oracle_mod, dof):
     assert worst < 1e-9, worst
 
 
+def composed_flow_table(g):
+    """The table golden G24 was generated on: synthetic SPOD data (K, nT) + the shipped long-time mean, AuvEnv's scaling - through the
+    numpy restatement of ReconstructedFlow.__init__ / scale (oracle/flow_ref.py, itself pinned by G12)."""
+    import os
+    from oracle import flow_ref
+    from marinevehiclereinforcementlearning_amd.synthetic import BASE_DT, synthetic_spod
+    from .conftest import GOLDEN
+    modes, coeffs = synthetic_spod(int(g["K"]), int(g["nT"]))
+    base = flow_ref.reconstruct(modes, coeffs, np.load(os.path.join(GOLDEN, "ltm.npy")))
+    bdx, bdy = flow_ref.grid_spacing(np.load(os.path.join(GOLDEN, "turbulence_coords.npy")))
+    fd, dx, dy, dt = flow_ref.scale(base, bdx, bdy, BASE_DT, *[float(v) for v in g["scale"]])
+    assert np.allclose([dx, dy, dt], g["flow_dxdydt"], rtol=1e-12)
+    return np.ascontiguousarray(fd[..., :2]), dt, dx, dy
+
+
+@pytest.mark.parametrize("dof", [3, 6])
+def test_fully_reference_composed_trajectories(oracle_mod, dof):
+    """G24: the 3/6-DoF + turbulence composition made ENTIRELY of executed reference code - ReconstructedFlow.interp (the reference
+    class, AuvEnv's scaling and sampling rule) feeding BlueROV2Heavy{3,6}DoF.derivs through their own velCurrent lines (6-DoF
+    hook-assisted), RK4 harness, fixed set-points inside the table: 8 envs x 36 steps.  The oracle's composition (table lookup at
+    time + offset and the pre-step position, held over the step; current resolved per RK stage; relative velocity in Ca / D) must
+    reproduce states, observations and controller memory to 1e-9."""
+    g = golden(f"g24_composed_{dof}dof.npz")
+    n_env, n_steps = g["states"].shape[0], g["states"].shape[1] - 1
+    uv, fdt, fdx, fdy = composed_flow_table(g)
+    env = oracle_mod.OracleRovEnv(dof, n_env, "f64", dt=float(g["dt"]), n_substeps=int(g["n_sub"]), fixed_setpoint=True, max_steps=10 ** 9,
+                                  flow=oracle_mod.FlowTable(uv, fdt, fdx, fdy))
+    npos = 3 if dof == 6 else 2
+    sp = g["sp"]
+    env.reset(np.concatenate([sp[:, :npos], sp[:, :npos], sp[:, npos:]], axis=1), toffset=g["toff"])
+    env.y[:] = g["start"]
+    worst = 0.0
+    for s in range(n_steps):
+        obs, _, _ = env.step(np.zeros((n_env, dof)))
+        worst = max(worst, max_scaled_err(env.y, g["states"][:, s + 1]), max_scaled_err(obs, g["obs"][:, s + 1]),
+                    max_scaled_err(env.eold, g["eOld"][:, s]), max_scaled_err(env.eint, g["eInt"][:, s]))
+    assert worst < 1e-9, worst
+
+
 @pytest.mark.parametrize("name,dof", [("g10_envstep_6dof_random.npz", 6), ("g10_envstep_6dof_fixedsp.npz", 6),
                                       ("g10_envstep_3dof_fixedsp.npz", 3)])
 def test_envstep_rk45_trajectories(oracle_mod, name, dof):
