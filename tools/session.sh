@@ -96,7 +96,7 @@ audits)
   export MVRL_CPU_THREADS=16 OMP_NUM_THREADS=16
   bash tools/gpu_steps.sh \
     "${R}_audit_c4|400|python tests/audit/episode_audit.py c4 65536 250" \
-    "${R}_audit_c4_t32|400|MVRL_LIB=variants_build/libmvrl_flowt32.so python tests/audit/episode_audit.py c4 65536 250" \
+    "${R}_audit_c4_t32|400|if [ -f variants_build/libmvrl_flowt32.so ]; then MVRL_LIB=variants_build/libmvrl_flowt32.so python tests/audit/episode_audit.py c4 65536 250; else echo 'A/B arm skipped: build it first in the container: python tools/variants.py build flowt32'; fi" \
     "${R}_audit_c3|400|python tests/audit/episode_audit.py c3 65536 250" \
     "${R}_audit_c2|400|python tests/audit/episode_audit.py c2 65536 250" \
     "${R}_audit_c4_f64|400|MVRL_AUDIT_PRECISION=f64 python tests/audit/episode_audit.py c4 65536 250" \
