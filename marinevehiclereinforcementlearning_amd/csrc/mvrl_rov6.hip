@@ -119,12 +119,26 @@ __device__ __forceinline__ void pid6(PP p, const float* z, Pid6& s, float half_d
 #pragma unroll
         for (int i = 0; i < 6; i++) s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
     }
+    float dev[6];
+#if defined(MVRL_YAW_INC_ON) && !defined(MVRL_INC_SELECT)
+    // inc_valid is wave-uniform (false only for the first PID call of an env step, whose predecessor belongs to the previous
+    // step): a scalar BRANCH, not six subtract-and-select pairs per call (the empty asm keeps the compiler from flattening it
+    // back into selects).  Same values either way.
+    if (USE_INC && inc_valid) {
+        asm volatile("");
+#pragma unroll
+        for (int i = 0; i < 5; i++) dev[i] = -dpose[i];
+        dev[5] = yaw_w - dpose[5];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) dev[i] = e[i] - s.eold[i];
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         float de = e[i] - s.eold[i];
         if (USE_INC) {
-            // inc_valid is wave-uniform (false only for the first PID call of an env step, whose predecessor belongs to
-            // the previous step).  x, y, z, phi, theta errors are plain differences sp - pose, so -dpose is their
+            // x, y, z, phi, theta errors are plain differences sp - pose, so -dpose is their
             // change; the yaw error can change branch (wrap at +-pi): its difference carries the wrap.
             const float di = -dpose[i];
 #ifdef MVRL_YAW_INC_ON
@@ -134,6 +148,12 @@ __device__ __forceinline__ void pid6(PP p, const float* z, Pid6& s, float half_d
             de = use ? di : de;
 #endif
         }
+        dev[i] = de;
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float de = dev[i];
         const float kdi = HAS_DT ? kd_inv[i] : p->kd[i] * 1e9f;
         float v = fmaf(p->ki[i], s.eint[i], fmaf(kdi, de, p->kp[i] * e[i]));
         u[i] = clampf(v, -p->umax[i], p->umax[i]);
@@ -416,6 +436,32 @@ struct Park12 {
             MVRL_PARK_LD(v, t, MVRL_PARK_PER * j);
         }
     }
+    // the first six values only (the pose rows: stage 2 of the FAITHFUL loop needs k1's pose half for the PID's increment)
+    __device__ __forceinline__ void get6(float* v) const {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 6 / MVRL_PARK_PER + (6 % MVRL_PARK_PER ? 1 : 0); j++) {
+            const park_vec t = const_cast<const park_vec&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]);
+            float w[MVRL_PARK_PER];
+            MVRL_PARK_LD(w, t, 0);
+#pragma unroll
+            for (int q = 0; q < MVRL_PARK_PER; q++)
+                if (MVRL_PARK_PER * j + q < 6) v[MVRL_PARK_PER * j + q] = w[q];
+        }
+    }
+#ifdef MVRL_PARK_DSADD
+    // acc += 2 k INSIDE the LDS (ds_add: no read, no write, nothing to wait for): 2 k is exact, the add rounds once - the same value as
+    // fma(2, k, acc) of the read-modify-write form.
+    __device__ __forceinline__ void add2(const float* k) const {
+        float* const b = reinterpret_cast<float*>(const_cast<park_vec*>(base));
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 12; q++)
+            __hip_atomic_fetch_add(&b[((q / MVRL_PARK_PER) * MVRL_STEP_BLOCK + threadIdx.x) * MVRL_PARK_PER + (q % MVRL_PARK_PER)], 2.f * k[q],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+    }
+#endif
 };
 // The set-point of the step: needed inside the RK4 loop only by lanes that take a full sincos (stage_trig) and after it (pose
 // = set-point - error, observation) - six registers the right-hand side can use instead.
@@ -1015,6 +1061,17 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 const Trig6 t2 = stage_trig<true>(tb, yt, dp, sps);
                 derivs6<SYM, FLOW, true, true>(p, yt, t2, pid, half_dtp, kd_inv, dp, true, cur, k, nullptr, fixed, e0s);
                 float d2[6], d3[6], a[12], yb[12];
+#ifdef MVRL_PARK_DSADD
+                // both reads leave first; the accumulator's update is an LDS-side add issued after the next stage's state is formed:
+                // nothing ever waits for it
+                park_a.get6(a);
+                park_y.get(yb);
+#pragma unroll
+                for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - a[q]); d2[q] = hh * k[q]; }
+#pragma unroll
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], yb[q]);
+                park_a.add2(k);
+#else
                 park_a.get(a);
 #pragma unroll
                 for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - a[q]); d2[q] = hh * k[q]; }
@@ -1024,9 +1081,16 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_y.get(yb);
 #pragma unroll
                 for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], yb[q]);
+#endif
                 derivs6<SYM, FLOW, false, true>(p, yt, stage3_trig(t2, tb, yt, dp, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, nullptr, fixed, e0s);
 #pragma unroll
                 for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
+#ifdef MVRL_PARK_DSADD
+                park_y.get(yb);
+#pragma unroll
+                for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -h : h, k[q], yb[q]);
+                park_a.add2(k);
+#else
                 park_a.get(a);
 #pragma unroll
                 for (int q = 0; q < 12; q++) a[q] = fmaf(2.f, k[q], a[q]);
@@ -1034,6 +1098,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_y.get(yb);
 #pragma unroll
                 for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -h : h, k[q], yb[q]);
+#endif
                 const Trig6 t4 = stage_trig<true>(tb, yt, d3, sps);
                 derivs6<SYM, FLOW, true, true>(p, yt, t4, pid, half_dtp, kd_inv, dp, true, cur, k, aux_last, fixed, e0s);
                 park_a.get(a);

@@ -18,6 +18,14 @@ VARIANTS = {
     "f64ilp": dict(extra=[], drop=(), f64=["-ffp-contract=fast", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
     "f64occ": dict(extra=[], drop=(), f64=["-ffp-contract=fast", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]),
     "f64fulltrig": dict(extra=["-DMVRL_FULL_STAGE_TRIG"], drop=()),
+    # round 5, second session: the PID's increment select as it was (six subtract-and-select pairs per first-stage call)
+    "incsel": dict(extra=["-DMVRL_INC_SELECT"], drop=()),
+    # RK4 slope accumulator updated inside the LDS (ds_add) instead of read-modify-write
+    "dsadd": dict(extra=["-DMVRL_PARK_DSADD"], drop=()),
+    # fp64 twins: no NaN / Inf / signed-zero bookkeeping, but IEEE division and the written order of operations
+    "f64fin": dict(extra=[], drop=(), f64=["-ffp-contract=fast", "-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"]),
+    "f64nolicm": dict(extra=[], drop=(), f64=["-ffp-contract=fast", "-mllvm", "-disable-machine-licm"]),
+    "f64fin_dsadd": dict(extra=["-DMVRL_PARK_DSADD"], drop=(), f64=["-ffp-contract=fast", "-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"]),
     # attribution (tests/audit/episode_audit.py): the round-4 fp32 turbulence sample time
     "flowt32": dict(extra=["-DMVRL_FLOW_TIME_F32"], drop=()),
     # profiling build: per-wave s_memtime stamps at the phase boundaries of the 6-DoF step kernel (tools/stamp_probe.py)
