@@ -21,9 +21,14 @@ struct Pid3 {
 // z: the pose in ERROR coordinates, z = setPoint - pose (yaw: the unwrapped difference) - see rov6_step_kernel in mvrl_rov6.hip.
 // e0 / fixed: with a fixed set-point the integrated variable is the displacement since the start of the step and the error is
 // e0 + z (see pid6 in mvrl_rov6.hip); `fixed` is wave-uniform.
+// where the timeHistory side outputs of a call go, if anywhere; `on` is wave-uniform: a scalar branch (AuxRow in mvrl_rov6.hip)
+struct AuxRow3 {
+    bool on;
+    float* row;
+};
 template <bool HAS_DT, bool USE_INC, class PP>
 __device__ __forceinline__ void control3(PP p, const float* z, Pid3& s, float dtp, float inv_den,
-                                         const float* dpose, bool inc_valid, float c, float sn, float* F, float* aux_row,
+                                         const float* dpose, bool inc_valid, float c, float sn, float* F, const AuxRow3& aux,
                                          bool fixed, const float* e0) {
     p = launder(p);
     float e[3] = {z[0], z[1], 0.f}, z2 = z[2];
@@ -42,7 +47,16 @@ __device__ __forceinline__ void control3(PP p, const float* z, Pid3& s, float dt
 #else
     e[2] = angle_error(z2, 0.f);
 #endif
-    float u[3];
+    float u[3], dev[3];
+#if defined(MVRL_YAW_INC3_ON) && !defined(MVRL_INC_SELECT)
+    if (USE_INC && inc_valid) {   // wave-uniform: a scalar branch (see pid6 in mvrl_rov6.hip)
+        asm volatile("");
+        dev[0] = -dpose[0]; dev[1] = -dpose[1]; dev[2] = yaw_w - dpose[2];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++) dev[i] = e[i] - s.eold[i];
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         float de = e[i] - s.eold[i];
@@ -55,6 +69,12 @@ __device__ __forceinline__ void control3(PP p, const float* z, Pid3& s, float dt
             de = use ? di : de;
 #endif
         }
+        dev[i] = de;
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float de = dev[i];
         // dtp / 2 and K_D / dt are the same for every call of a step: loop-invariant products (literals x one register in the
         // baked flavour), hoisted by the compiler
         if (HAS_DT) s.eint[i] = fmaf(s.eold[i] + e[i], 0.5f * dtp, s.eint[i]);
@@ -64,13 +84,19 @@ __device__ __forceinline__ void control3(PP p, const float* z, Pid3& s, float dt
         s.eold[i] = e[i];
     }
     float Xd = u[0] * c + u[1] * sn, Yd = -u[0] * sn + u[1] * c, Nd = u[2];
-    if (aux_row) { aux_row[0] = Xd; aux_row[1] = Yd; aux_row[2] = Nd; }  // timeHistory F0..F2 (3DoF.py:498-507)
+    float cvs[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         float cv = fmaf(p->Ainv[3 * i + 2], Nd, fmaf(p->Ainv[3 * i + 1], Yd, p->Ainv[3 * i] * Xd));
         float f = clampf(cv, -p->f_max, p->f_max);   // rpm clamp +-3500 and dead-band 300 in force space (3DoF.py:171-180)
         F[i] = (fabsf(f) < p->f_dead) ? 0.f : f;
-        if (aux_row) aux_row[3 + i] = fsign(cv) * sqrtf(fabsf(cv) * p->inv_thrust_k) * 60.f;  // u0..u3 [rpm]
+        cvs[i] = cv;
+    }
+    if (aux.on) {
+        float* const aux_row = aux.row;
+        aux_row[0] = Xd; aux_row[1] = Yd; aux_row[2] = Nd;   // timeHistory F0..F2 (3DoF.py:498-507)
+#pragma unroll
+        for (int i = 0; i < 4; i++) aux_row[3 + i] = fsign(cvs[i]) * sqrtf(fabsf(cvs[i]) * p->inv_thrust_k) * 60.f;  // u0..u3 [rpm]
     }
 }
 
@@ -100,7 +126,16 @@ __device__ __forceinline__ void dynamics3(PP p, const float* y, float c, float s
         // |u| / max(1e-5, uJet) = |u| * min(1e5, 1 / sqrt(|F| / k)): one v_rsq instead of v_sqrt + v_rcp (rsq(0) = inf -> 1e5)
         float q = au * fminf(1e5f, __builtin_amdgcn_rsqf(fabsf(F[i]) * p->inv_jet_area_k));
 #endif
+#if MVRL_F64 || defined(MVRL_LIB_EXP)
         float dCd = p->jet_c1 * expf(-p->jet_k1 * q) + p->jet_c2 * expf(-p->jet_k2 * q);
+#else
+        // exp(-k q) = exp2(q * (-k log2 e)): ONE multiply (the constant product folds in the baked flavour) and v_exp_f32.  The library
+        // expf wraps the same v_exp_f32 in six more instructions per call (compare, two selects, a scaled second multiply ...) so that
+        // results below 2^-126 come out as denormals; here they are flushed (|error| < 1.2e-38 on a factor of order one) - and a lone
+        // wave per SIMD (C2) pays 2.2 ns for every instruction: 48 fewer per RK stage, -22 % of the 3-DoF stage.
+        float dCd = p->jet_c1 * __builtin_amdgcn_exp2f(q * (-1.44269504088896341f * p->jet_k1))
+                  + p->jet_c2 * __builtin_amdgcn_exp2f(q * (-1.44269504088896341f * p->jet_k2));
+#endif
         Xsum += dCd * drag;
     }
     float H[3];
@@ -156,7 +191,13 @@ __device__ __forceinline__ Trig1 stage_trig1(const Trig1& b, float d, float sp_p
     Trig1 t;
     t.s = fmaf(b.c, sd, b.s * cd);
     t.c = fmaf(-b.s, sd, b.c * cd);
+#ifndef MVRL_NO_TRIG_VOTE
+    if (__builtin_expect(__any(fabsf(d) > 0.25f) != 0, 0)) {   // the common case falls through one not-taken scalar branch
+        if (fabsf(d) > 0.25f) t = trig1(sp_psi - z_psi);
+    }
+#else
     if (fabsf(d) > 0.25f) t = trig1(sp_psi - z_psi);
+#endif
     return t;
 #endif
 }
@@ -164,10 +205,10 @@ __device__ __forceinline__ Trig1 stage_trig1(const Trig1& b, float d, float sp_p
 // y: [error coordinates of the pose (3) | body velocities (3)]; t: sin / cos of the stage's heading
 template <bool FLOW, bool HAS_DT, class PP>
 __device__ __forceinline__ void derivs3(PP p, const float* y, const Trig1& t, Pid3& pid, float dtp, float inv_den,
-                                        const float* dpose, bool inc_valid, float2 cur, float* dy, float* aux_row, bool fixed,
+                                        const float* dpose, bool inc_valid, float2 cur, float* dy, const AuxRow3& aux, bool fixed,
                                         const float* e0) {
     float F[4];
-    control3<HAS_DT, true>(p, y, pid, dtp, inv_den, dpose, inc_valid, t.c, t.s, F, aux_row, fixed, e0);
+    control3<HAS_DT, true>(p, y, pid, dtp, inv_den, dpose, inc_valid, t.c, t.s, F, aux, fixed, e0);
     dynamics3<FLOW>(p, y, t.c, t.s, F, cur, dy);
 }
 
@@ -364,7 +405,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
 #define MVRL_AX3(c_, q_) ((q_) < 3 ? -(c_) : (c_))
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[6], acc[6], yt[6];
-        float* const aux_last = (ks == io.n_sub - 1) ? aux_row : nullptr;
+        const AuxRow3 aux_last{io.aux != nullptr && ks == io.n_sub - 1, aux_row}, aux_none{false, nullptr};
 #if MVRL_BAM
         // ZOH: every sub-step; FAITHFUL: re-anchored every fourth - at the binary start heading + what the step has turned so far
         if (ks > 0 && (ZOH || (ks & 3) == 0)) sincos_bam(bam_add(bpsi, z0[2] - y[2]), tb.s, tb.c);
@@ -394,17 +435,17 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
             float dp[3], d2[3], d3[3];
 #pragma unroll
             for (int q = 0; q < 3; q++) dp[q] = inc_prev[q];
-            derivs3<FLOW, false>(p, y, tb, pid, 0.f, 1e9f, dp, ks > 0, cur, k, nullptr, fixed, e0);
+            derivs3<FLOW, false>(p, y, tb, pid, 0.f, 1e9f, dp, ks > 0, cur, k, aux_none, fixed, e0);
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(MVRL_AX3(hh, q), k[q], y[q]); }
 #pragma unroll
             for (int q = 0; q < 3; q++) dp[q] = hh * k[q];
-            derivs3<FLOW, true>(p, yt, stage_trig1(tb, dp[2], org[2], yt[2]), pid, hh, inv_hh, dp, true, cur, k, nullptr, fixed, e0);
+            derivs3<FLOW, true>(p, yt, stage_trig1(tb, dp[2], org[2], yt[2]), pid, hh, inv_hh, dp, true, cur, k, aux_none, fixed, e0);
 #pragma unroll
             for (int q = 0; q < 3; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(MVRL_AX3(hh, q), k[q], y[q]); }
-            derivs3<FLOW, false>(p, yt, stage_trig1(tb, d2[2], org[2], yt[2]), pid, 0.f, 1e9f, dp, true, cur, k, nullptr, fixed, e0);
+            derivs3<FLOW, false>(p, yt, stage_trig1(tb, d2[2], org[2], yt[2]), pid, 0.f, 1e9f, dp, true, cur, k, aux_none, fixed, e0);
 #pragma unroll
             for (int q = 0; q < 3; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
 #pragma unroll

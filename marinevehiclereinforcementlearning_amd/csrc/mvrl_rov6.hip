@@ -115,7 +115,11 @@ __device__ __forceinline__ void pid6(PP p, const float* z, Pid6& s, float half_d
 #pragma unroll
         for (int i = 0; i < 6; i++) s.eint[i] = fmaf(s.eold[i] + e[i], half_dtp, s.eint[i]);
     }
+#ifndef MVRL_NO_TRIG_VOTE
+    if (__builtin_expect(windup_any, fixed)) {   // action mode: out of line, the common case falls through
+#else
     if (windup_any) {
+#endif
 #pragma unroll
         for (int i = 0; i < 6; i++) s.eint[i] = (fabsf(e[i]) > p->windup[i]) ? 0.f : s.eint[i];
     }
@@ -436,32 +440,6 @@ struct Park12 {
             MVRL_PARK_LD(v, t, MVRL_PARK_PER * j);
         }
     }
-    // the first six values only (the pose rows: stage 2 of the FAITHFUL loop needs k1's pose half for the PID's increment)
-    __device__ __forceinline__ void get6(float* v) const {
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int j = 0; j < 6 / MVRL_PARK_PER + (6 % MVRL_PARK_PER ? 1 : 0); j++) {
-            const park_vec t = const_cast<const park_vec&>(base[j * MVRL_STEP_BLOCK + threadIdx.x]);
-            float w[MVRL_PARK_PER];
-            MVRL_PARK_LD(w, t, 0);
-#pragma unroll
-            for (int q = 0; q < MVRL_PARK_PER; q++)
-                if (MVRL_PARK_PER * j + q < 6) v[MVRL_PARK_PER * j + q] = w[q];
-        }
-    }
-#ifdef MVRL_PARK_DSADD
-    // acc += 2 k INSIDE the LDS (ds_add: no read, no write, nothing to wait for): 2 k is exact, the add rounds once - the same value as
-    // fma(2, k, acc) of the read-modify-write form.
-    __device__ __forceinline__ void add2(const float* k) const {
-        float* const b = reinterpret_cast<float*>(const_cast<park_vec*>(base));
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < 12; q++)
-            __hip_atomic_fetch_add(&b[((q / MVRL_PARK_PER) * MVRL_STEP_BLOCK + threadIdx.x) * MVRL_PARK_PER + (q % MVRL_PARK_PER)], 2.f * k[q],
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("" ::: "memory");
-    }
-#endif
 };
 // The set-point of the step: needed inside the RK4 loop only by lanes that take a full sincos (stage_trig) and after it (pose
 // = set-point - error, observation) - six registers the right-hand side can use instead.
@@ -552,7 +530,15 @@ __device__ __forceinline__ Trig6 stage_trig(const Trig6& b, const float* yt, con
     // take the full evaluation as a DIVERGENT branch: the wave issues those ~80 instructions with one or two lanes enabled.
     // The chip runs this kernel at its power limit, where an instruction's cost is the lanes it
     // switches, not its issue slot - cheaper than sending all 64 lanes through the full evaluation whenever one needs it.
+#ifndef MVRL_NO_TRIG_VOTE
+    // a wave in which no lane needs it pays one compare and one not-taken scalar branch instead of compare + s_and_saveexec +
+    // taken branch + exec restore (tools/valu_branch.hip: 2.9 instead of 5.3 ns per guard at four waves per SIMD, 8 instead of 30 at two)
+    if (__builtin_expect(__any(m > 0.25f) != 0, 0)) {
+        if (m > 0.25f) t = MVRL_FULL_TRIG();
+    }
+#else
     if (m > 0.25f) t = MVRL_FULL_TRIG();
+#endif
 #endif
     return t;
 #endif
@@ -586,7 +572,13 @@ __device__ __forceinline__ Trig6 stage3_trig(const Trig6& t2, const Trig6& tb, c
     t.sth = fmaf(t2.cth, sd[1], t2.sth * cd[1]); t.cth = fmaf(-t2.sth, sd[1], t2.cth * cd[1]);
     t.sps = fmaf(t2.cps, sd[2], t2.sps * cd[2]); t.cps = fmaf(-t2.sps, sd[2], t2.cps * cd[2]);
     const float m = fmaxf(fmaxf(fabsf(eps[3]), fabsf(eps[4])), fabsf(eps[5]));
+#ifndef MVRL_NO_TRIG_VOTE
+    if (__builtin_expect(__any(m > 0.05f) != 0, 0)) {
+        if (m > 0.05f) t = stage_trig<true>(tb, yt, d2, sp);
+    }
+#else
     if (m > 0.05f) t = stage_trig<true>(tb, yt, d2, sp);
+#endif
     return t;
 #endif
 }
@@ -623,16 +615,23 @@ __device__ __forceinline__ void write_aux6(PP p, const float* u, const float* cv
     for (int q = 0; q < 8; q++) aux_row[6 + q] = force_to_rpm(p, cv[q]);
 }
 
+// Where the timeHistory side outputs of an RHS call go, if anywhere.  `on` is WAVE-UNIFORM (kernel argument and loop counter): the
+// test is a scalar branch - a per-lane test of the row pointer cost a 64-bit compare, two selects and an exec guard per sub-step
+// for a feature that is off in every roll-out.
+struct AuxRow {
+    bool on;
+    float* row;
+};
 template <bool SYM, bool FLOW, bool HAS_DT, bool USE_INC, class PP>
 __device__ __forceinline__ void derivs6(PP p, const float* y, const Trig6& t, Pid6& pid, float half_dtp,
                                         const float* kd_inv, const float* dpose, bool inc_valid, float2 cur, float* dy,
-                                        float* aux_row, bool fixed, const SpStore& e0s) {
+                                        const AuxRow& aux, bool fixed, const SpStore& e0s) {
     // y: [error coordinates of the pose (6) | body velocities (6)]
     Axes ax = body_axes(t);
     float u[6], F[8], cv[8];
     pid6<HAS_DT, USE_INC>(p, y, pid, half_dtp, kd_inv, dpose, inc_valid, u, fixed, e0s);
     allocate6<SYM>(p, ax, u, F, cv);
-    if (aux_row) write_aux6(p, u, cv, aux_row);  // wave-uniform: last RHS call of the step, aux enabled
+    if (aux.on) write_aux6(p, u, cv, aux.row);  // wave-uniform: last RHS call of the step, aux enabled
     dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, dy);
 }
 
@@ -960,7 +959,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
     for (int ks = 0; ks < io.n_sub; ks++) {
         float k[12], acc[12], yt[12];
         float tb_inc[3] = {0.f, 0.f, 0.f};
-        float* const aux_last = (ks == io.n_sub - 1) ? aux_row : nullptr;
+        const AuxRow aux_last{io.aux != nullptr && ks == io.n_sub - 1, aux_row}, aux_none{false, nullptr};
         if (ZOH) {
             // PID + allocation once per sub-step; t - tOld = h except for the very first call after reset (= 0)
             Trig6 t = tb;
@@ -976,7 +975,7 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             else pid6<true, true>(p, y, pid, half_dtp, kd_inv, inc_prev, ks > 0, u, fixed, e0s);
             float cvz[8];
             allocate6<SYM>(p, ax, u, F, cvz);
-            if (aux_last) write_aux6(p, u, cvz, aux_last);
+            if (aux_last.on) write_aux6(p, u, cvz, aux_last.row);
             dynamics6<SYM, FLOW>(p, y, t, ax, F, cur, k);
             float dz[6];
 #ifdef MVRL_PARK_ON
@@ -1052,26 +1051,15 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
             {
                 // same arithmetic, same order of operations as below; y and acc live in LDS between the stages
                 park_y.put(y);
-                derivs6<SYM, FLOW, false, true>(p, y, tb, pid, 0.f, nullptr, dp, ks > 0, cur, k, nullptr, fixed, e0s);
+                derivs6<SYM, FLOW, false, true>(p, y, tb, pid, 0.f, nullptr, dp, ks > 0, cur, k, aux_none, fixed, e0s);
                 park_a.put(k);
 #pragma unroll
                 for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]);
 #pragma unroll
                 for (int q = 0; q < 6; q++) dp[q] = hh * k[q];
                 const Trig6 t2 = stage_trig<true>(tb, yt, dp, sps);
-                derivs6<SYM, FLOW, true, true>(p, yt, t2, pid, half_dtp, kd_inv, dp, true, cur, k, nullptr, fixed, e0s);
+                derivs6<SYM, FLOW, true, true>(p, yt, t2, pid, half_dtp, kd_inv, dp, true, cur, k, aux_none, fixed, e0s);
                 float d2[6], d3[6], a[12], yb[12];
-#ifdef MVRL_PARK_DSADD
-                // both reads leave first; the accumulator's update is an LDS-side add issued after the next stage's state is formed:
-                // nothing ever waits for it
-                park_a.get6(a);
-                park_y.get(yb);
-#pragma unroll
-                for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - a[q]); d2[q] = hh * k[q]; }
-#pragma unroll
-                for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], yb[q]);
-                park_a.add2(k);
-#else
                 park_a.get(a);
 #pragma unroll
                 for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - a[q]); d2[q] = hh * k[q]; }
@@ -1081,16 +1069,9 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_y.get(yb);
 #pragma unroll
                 for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -hh : hh, k[q], yb[q]);
-#endif
-                derivs6<SYM, FLOW, false, true>(p, yt, stage3_trig(t2, tb, yt, dp, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, nullptr, fixed, e0s);
+                derivs6<SYM, FLOW, false, true>(p, yt, stage3_trig(t2, tb, yt, dp, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, aux_none, fixed, e0s);
 #pragma unroll
                 for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
-#ifdef MVRL_PARK_DSADD
-                park_y.get(yb);
-#pragma unroll
-                for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -h : h, k[q], yb[q]);
-                park_a.add2(k);
-#else
                 park_a.get(a);
 #pragma unroll
                 for (int q = 0; q < 12; q++) a[q] = fmaf(2.f, k[q], a[q]);
@@ -1098,7 +1079,6 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 park_y.get(yb);
 #pragma unroll
                 for (int q = 0; q < 12; q++) yt[q] = fmaf(q < 6 ? -h : h, k[q], yb[q]);
-#endif
                 const Trig6 t4 = stage_trig<true>(tb, yt, d3, sps);
                 derivs6<SYM, FLOW, true, true>(p, yt, t4, pid, half_dtp, kd_inv, dp, true, cur, k, aux_last, fixed, e0s);
                 park_a.get(a);
@@ -1119,19 +1099,19 @@ __global__ MVRL_STEP_BOUNDS6 void rov6_step_kernel(const Rov6Dev* __restrict__ p
                 continue;
             }
 #endif
-            derivs6<SYM, FLOW, false, true>(p, y, tb, pid, 0.f, nullptr, dp, ks > 0, cur, k, nullptr, fixed, e0s);
+            derivs6<SYM, FLOW, false, true>(p, y, tb, pid, 0.f, nullptr, dp, ks > 0, cur, k, aux_none, fixed, e0s);
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = k[q]; yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]); }
 #pragma unroll
             for (int q = 0; q < 6; q++) dp[q] = hh * k[q];                       // (y + hh k1) - y
             const Trig6 t2 = stage_trig<true>(tb, yt, dp, sps);
-            derivs6<SYM, FLOW, true, true>(p, yt, t2, pid, half_dtp, kd_inv, dp, true, cur, k, nullptr, fixed, e0s);
+            derivs6<SYM, FLOW, true, true>(p, yt, t2, pid, half_dtp, kd_inv, dp, true, cur, k, aux_none, fixed, e0s);
             float d2[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }  // hh (k2 - k1)
 #pragma unroll
             for (int q = 0; q < 12; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(q < 6 ? -hh : hh, k[q], y[q]); }
-            derivs6<SYM, FLOW, false, true>(p, yt, stage3_trig(t2, tb, yt, dp, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, nullptr, fixed, e0s);
+            derivs6<SYM, FLOW, false, true>(p, yt, stage3_trig(t2, tb, yt, dp, d2, sps), pid, 0.f, nullptr, dp, true, cur, k, aux_none, fixed, e0s);
             float d3[6];
 #pragma unroll
             for (int q = 0; q < 6; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }          // h k3 - hh k2

@@ -19,13 +19,11 @@ VARIANTS = {
     "f64occ": dict(extra=[], drop=(), f64=["-ffp-contract=fast", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]),
     "f64fulltrig": dict(extra=["-DMVRL_FULL_STAGE_TRIG"], drop=()),
     # round 5, second session: the PID's increment select as it was (six subtract-and-select pairs per first-stage call)
+    "notrigvote": dict(extra=["-DMVRL_NO_TRIG_VOTE"], drop=()),   # rare per-lane fall-backs as plain exec guards (before this session: C2 +5 %)
     "incsel": dict(extra=["-DMVRL_INC_SELECT"], drop=()),
-    # RK4 slope accumulator updated inside the LDS (ds_add) instead of read-modify-write
-    "dsadd": dict(extra=["-DMVRL_PARK_DSADD"], drop=()),
     # fp64 twins: no NaN / Inf / signed-zero bookkeeping, but IEEE division and the written order of operations
-    "f64fin": dict(extra=[], drop=(), f64=["-ffp-contract=fast", "-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"]),
+    "f64nofin": dict(extra=[], drop=(), f64=["-ffp-contract=fast"]),     # the fp64 twins WITH NaN / Inf / signed-zero bookkeeping (first session of round 5)
     "f64nolicm": dict(extra=[], drop=(), f64=["-ffp-contract=fast", "-mllvm", "-disable-machine-licm"]),
-    "f64fin_dsadd": dict(extra=["-DMVRL_PARK_DSADD"], drop=(), f64=["-ffp-contract=fast", "-fno-honor-nans", "-fno-honor-infinities", "-fno-signed-zeros"]),
     # attribution (tests/audit/episode_audit.py): the round-4 fp32 turbulence sample time
     "flowt32": dict(extra=["-DMVRL_FLOW_TIME_F32"], drop=()),
     # profiling build: per-wave s_memtime stamps at the phase boundaries of the 6-DoF step kernel (tools/stamp_probe.py)
