@@ -20,6 +20,7 @@ VARIANTS = {
     "f64fulltrig": dict(extra=["-DMVRL_FULL_STAGE_TRIG"], drop=()),
     # round 5, second session: the PID's increment select as it was (six subtract-and-select pairs per first-stage call)
     "notrigvote": dict(extra=["-DMVRL_NO_TRIG_VOTE"], drop=()),   # rare per-lane fall-backs as plain exec guards (before this session: C2 +5 %)
+    "libexp": dict(extra=["-DMVRL_LIB_EXP"], drop=()),   # the 3-DoF jet-drag factors through the library expf (before this session: C2 +18 %)
     "incsel": dict(extra=["-DMVRL_INC_SELECT"], drop=()),
     # fp64 twins: no NaN / Inf / signed-zero bookkeeping, but IEEE division and the written order of operations
     "f64nofin": dict(extra=[], drop=(), f64=["-ffp-contract=fast"]),     # the fp64 twins WITH NaN / Inf / signed-zero bookkeeping (first session of round 5)
@@ -32,6 +33,10 @@ VARIANTS = {
     "novs": dict(extra=["-DMVRL_NO_VGPR_SCALARS"], drop=()),          # RK step sizes left in SGPRs
     "auvscatter": dict(extra=["-DMVRL_AUV_LDS_OBS=0"], drop=()),      # AuvEnv observations stored row-per-lane
     # ("blk256", -DMVRL_STEP_BLOCK=256, measured +2 % in round 2, no longer builds: the LDS parking tiles are sized for one-wave blocks)
+    # two / four waves per workgroup: fewer workgroup launches per grid (the dependent-launch gap grows with the grid: 3.3 us at 1 024 one-wave
+    # workgroups, 5.8 us at 16 384); the parking tiles scale with the block
+    "blk128": dict(extra=["-DMVRL_STEP_BLOCK=128", "-DMVRL_PARK_FLOAT4S=(1280*(4/MVRL_PARK_PER))"], drop=()),
+    "blk256": dict(extra=["-DMVRL_STEP_BLOCK=256", "-DMVRL_PARK_FLOAT4S=(2560*(4/MVRL_PARK_PER))"], drop=()),
     "blk32": dict(extra=["-DMVRL_STEP_BLOCK=32"], drop=()),           # half-filled waves: twice the waves for a launch-bound batch (C2)
     "slp": dict(extra=[], drop=("-fno-slp-vectorize",)),
     "nofast": dict(extra=[], drop=("-ffast-math",)),
