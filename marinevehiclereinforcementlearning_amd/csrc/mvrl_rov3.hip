@@ -32,7 +32,11 @@ __device__ __forceinline__ void control3(PP p, const float* z, Pid3& s, float dt
                                          bool fixed, const float* e0) {
     p = launder(p);
     float e[3] = {z[0], z[1], 0.f}, z2 = z[2];
-    if (fixed) { e[0] += e0[0]; e[1] += e0[1]; z2 += e0[2]; }
+    // e0: the offset of the controller's error against the integrated variable - setPoint - pose_start with a fixed set-point, ZERO in the
+    // action mode (the caller's `ec`): added unconditionally (z + 0 is z), where a test of the wave-uniform `fixed` became three
+    // add-and-select pairs per call
+    e[0] += e0[0]; e[1] += e0[1]; z2 += e0[2];
+    (void)fixed;
 #if !defined(MVRL_NO_YAW_INC)
     // yaw error carried from call to call inside an env step (see pid6): previous error minus the yaw increment, wrapped
     float yaw_w = 0.f;
@@ -371,6 +375,7 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
     float2 cur = make_float2(0.f, 0.f);
     if (FLOW) cur = flow_combine(tap);
     if (first) { pid.eold[0] = e0[0]; pid.eold[1] = e0[1]; pid.eold[2] = angle_error(e0[2], 0.f); }
+    const float ec[3] = {fixed ? e0[0] : 0.f, fixed ? e0[1] : 0.f, fixed ? e0[2] : 0.f};   // what the controller adds to z (see control3)
 
     const float h_s = io.dt / (float)io.n_sub;
     const float h = in_vgpr(h_s), hh = in_vgpr(0.5f * h_s), h6 = in_vgpr(h_s / 6.f), inv_hh = in_vgpr(1.0f / (0.5f * h_s));
@@ -414,8 +419,8 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
 #endif
         if (ZOH) {
             float F[4];
-            if (first && ks == 0) control3<false, false>(p, y, pid, 0.f, 1e9f, nullptr, false, tb.c, tb.s, F, aux_last, fixed, e0);
-            else control3<true, true>(p, y, pid, h, 1.0f / h, inc_prev, ks > 0, tb.c, tb.s, F, aux_last, fixed, e0);
+            if (first && ks == 0) control3<false, false>(p, y, pid, 0.f, 1e9f, nullptr, false, tb.c, tb.s, F, aux_last, fixed, ec);
+            else control3<true, true>(p, y, pid, h, 1.0f / h, inc_prev, ks > 0, tb.c, tb.s, F, aux_last, fixed, ec);
             dynamics3<FLOW>(p, y, tb.c, tb.s, F, cur, k);
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(MVRL_AX3(hh, q), k[q], y[q]); }
@@ -435,22 +440,22 @@ __global__ MVRL_STEP_BOUNDS void rov3_step_kernel(const Rov3Dev* __restrict__ pg
             float dp[3], d2[3], d3[3];
 #pragma unroll
             for (int q = 0; q < 3; q++) dp[q] = inc_prev[q];
-            derivs3<FLOW, false>(p, y, tb, pid, 0.f, 1e9f, dp, ks > 0, cur, k, aux_none, fixed, e0);
+            derivs3<FLOW, false>(p, y, tb, pid, 0.f, 1e9f, dp, ks > 0, cur, k, aux_none, fixed, ec);
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = k[q]; yt[q] = fmaf(MVRL_AX3(hh, q), k[q], y[q]); }
 #pragma unroll
             for (int q = 0; q < 3; q++) dp[q] = hh * k[q];
-            derivs3<FLOW, true>(p, yt, stage_trig1(tb, dp[2], org[2], yt[2]), pid, hh, inv_hh, dp, true, cur, k, aux_none, fixed, e0);
+            derivs3<FLOW, true>(p, yt, stage_trig1(tb, dp[2], org[2], yt[2]), pid, hh, inv_hh, dp, true, cur, k, aux_none, fixed, ec);
 #pragma unroll
             for (int q = 0; q < 3; q++) { dp[q] = hh * (k[q] - acc[q]); d2[q] = hh * k[q]; }
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(MVRL_AX3(hh, q), k[q], y[q]); }
-            derivs3<FLOW, false>(p, yt, stage_trig1(tb, d2[2], org[2], yt[2]), pid, 0.f, 1e9f, dp, true, cur, k, aux_none, fixed, e0);
+            derivs3<FLOW, false>(p, yt, stage_trig1(tb, d2[2], org[2], yt[2]), pid, 0.f, 1e9f, dp, true, cur, k, aux_none, fixed, ec);
 #pragma unroll
             for (int q = 0; q < 3; q++) { d3[q] = h * k[q]; dp[q] = d3[q] - d2[q]; }
 #pragma unroll
             for (int q = 0; q < 6; q++) { acc[q] = fmaf(2.f, k[q], acc[q]); yt[q] = fmaf(MVRL_AX3(h, q), k[q], y[q]); }
-            derivs3<FLOW, true>(p, yt, stage_trig1(tb, d3[2], org[2], yt[2]), pid, hh, inv_hh, dp, true, cur, k, aux_last, fixed, e0);
+            derivs3<FLOW, true>(p, yt, stage_trig1(tb, d3[2], org[2], yt[2]), pid, hh, inv_hh, dp, true, cur, k, aux_last, fixed, ec);
 #pragma unroll
             for (int q = 0; q < 3; q++) inc_prev[q] = h6 * (acc[q] + k[q]) - d3[q];
         }
