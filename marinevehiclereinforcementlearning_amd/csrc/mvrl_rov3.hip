@@ -10,6 +10,12 @@
 
 namespace mvrl {
 
+// where the timeHistory side outputs of a call go, if anywhere; `on` is wave-uniform: a scalar branch (AuxRow in mvrl_rov6.hip)
+struct AuxRow3 {
+    bool on;
+    float* row;
+};
+
 struct Pid3 {
     float eold[3];
     float eint[3];
@@ -21,11 +27,6 @@ struct Pid3 {
 // z: the pose in ERROR coordinates, z = setPoint - pose (yaw: the unwrapped difference) - see rov6_step_kernel in mvrl_rov6.hip.
 // e0 / fixed: with a fixed set-point the integrated variable is the displacement since the start of the step and the error is
 // e0 + z (see pid6 in mvrl_rov6.hip); `fixed` is wave-uniform.
-// where the timeHistory side outputs of a call go, if anywhere; `on` is wave-uniform: a scalar branch (AuxRow in mvrl_rov6.hip)
-struct AuxRow3 {
-    bool on;
-    float* row;
-};
 template <bool HAS_DT, bool USE_INC, class PP>
 __device__ __forceinline__ void control3(PP p, const float* z, Pid3& s, float dtp, float inv_den,
                                          const float* dpose, bool inc_valid, float c, float sn, float* F, const AuxRow3& aux,
