@@ -72,7 +72,9 @@ __device__ inline int rk45_solve(RHS& f, double t0, double t_bound, double max_s
     double h_last = 0.0;
     int status = 0;
     while (t != t_bound) {  // OdeSolver.step until finished
-        const double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+        // (scipy: nextafter(t, direction * inf); the largest finite double gives the same neighbour and stays defined when the build
+        // tells the compiler that infinities do not occur)
+        const double min_step = 10 * fabs(nextafter(t, 1.7976931348623157e308) - t);
         double ha = (h_abs > max_step) ? max_step : ((h_abs < min_step) ? min_step : h_abs);
         bool accepted = false, rejected = false;
         double t_new = t, h = 0.0;

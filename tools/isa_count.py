@@ -6,7 +6,10 @@
                                                             fast path, in the divergent blocks (full sincos of single lanes), and
                                                             outside the loop; registers, scratch.
 The executed count (SQ_INSTS_VALU / SQ_WAVES on the GPU) is about n_sub x fast path + prologue/epilogue + the divergent blocks
-that were taken; this is the number to watch while editing the kernel."""
+that were taken; this is the number to watch while editing the kernel.
+(Round 5, second sitting: the rare fall-back blocks now sit OUT OF LINE behind wave votes; the walker below follows the layout of the
+fp32 instances, but splits the fp64 instance wrongly - for that one read registers / scratch here and take the instruction count from
+the GPU: tools/valu_count.sh, profiles/<round>_counters.json.)"""
 import os
 import re
 import subprocess
@@ -59,6 +62,8 @@ def analyse(path, sym, loop_depth=2):
         is_valu = bool(re.match(r"^\s+v_", l))
         if depth >= loop_depth:
             if skip_to is not None:
+                if not slow:          # a divergent region entered outside the loop and still open inside it (out-of-line fall-back blocks)
+                    slow.append(0)
                 slow[-1] += is_valu
             else:
                 fast += is_valu
