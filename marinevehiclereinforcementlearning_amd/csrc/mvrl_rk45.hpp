@@ -80,6 +80,11 @@ __device__ inline int rk45_solve(RHS& f, double t0, double t_bound, double max_s
         double t_new = t, h = 0.0;
         while (!accepted) {
             if (ha < min_step) { status = -1; break; }  // TOO_SMALL_STEP
+            // Not in scipy: an exit every lane reaches whatever its numbers are.  A non-finite state makes `err` a NaN; scipy's loop then
+            // shrinks the step (fmax(0.2, NaN) = 0.2) until TOO_SMALL_STEP ends it, but this file is compiled with -fno-honor-nans, under
+            // which the compiler owes a NaN nothing - and a lane that never leaves this loop takes the GPU with it.  The reference's own
+            // steps take 10^2 ... 10^3 right-hand-side calls.
+            if (calls > 2000000) { status = -2; break; }
             h = ha;
             t_new = t + h;
             if (t_new - t_bound > 0) t_new = t_bound;

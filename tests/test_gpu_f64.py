@@ -114,6 +114,34 @@ def test_rk45_config1_3dof_1000_random_steps_on_gpu():
     assert np.mean(nfev == g["ncalls"]) > 0.999
 
 
+@pytest.mark.timeout(180)
+def test_rk45_lane_with_a_non_finite_state_ends_its_step():
+    """scipy's RK45 loop leaves a NaN error norm behind by shrinking the step (fmax(0.2, NaN) = 0.2) until TOO_SMALL_STEP; the fp64 twins
+    are compiled with -fno-honor-nans, under which the compiler owes a NaN nothing, so the kernel carries an exit of its own
+    (mvrl_rk45.hpp).  A lane whose state is not finite must end its step - a wave that never ends takes the GPU with it - and must not
+    disturb the lanes beside it."""
+    n = 64
+    rng = np.random.default_rng(3)
+    init = np.concatenate([(rng.random((n, 6)) - 0.5) * 2.0, rng.random((n, 3)) * 2 * np.pi], axis=1)
+    act = rng.uniform(-1, 1, size=(n, 6))
+    out = []
+    for poison in (False, True):
+        h = _lib.Handle(P.make_config("rov6", n, auto_reset=False, max_steps=10 ** 9, use_flow=False, precision="f64", integrator="rk45"))
+        h.reset(init=init)
+        if poison:
+            st = h.get_state()
+            st[6, 5] = np.nan          # plane 6 = surge velocity u (include/mvrl.h), env 5
+            h.set_state(st)
+        h.step(act)
+        out.append((h.get_state().copy(), h.get_nfev().copy()))
+        h.close()
+    (clean, nf0), (pois, nf1) = out
+    others = np.arange(n) != 5
+    assert np.array_equal(clean[:, others], pois[:, others])       # lanes are independent: bit for bit
+    assert np.array_equal(nf0[others], nf1[others])
+    assert np.isfinite(clean).all() and nf1[5] <= 2000007          # the poisoned lane ended (at the latest by the kernel's own exit)
+
+
 def test_f64_auvenv_golden():
     from oracle import flow_ref
     g = golden("g13_auvenv.npz")
