@@ -195,6 +195,35 @@ def ensemble_sensitive(oracle_mod, dof, init, actions, lanes, until, env_kw=None
     return (sens, med) if return_median else sens
 
 
+def ensemble_deviation(oracle_mod, dof, init, actions, lanes, env_kw=None, toffset=None, members=64, noise=1e-15, seed=1):
+    """How far does the fp64 REFERENCE move when it is perturbed at the level of its own roundings?  For each lane, `members` fp64 oracle
+    runs whose state is multiplied by 1 + noise * U(-1, 1) after every RK4 sub-step, against the unperturbed run: the largest scaled
+    deviation of a member per step, dev[step, lane].  Where that is not small, two fp64 evaluations of the reference's formulas cannot
+    agree (a vehicle passing theta = +-90 deg: J2 ~ 1 / cos(theta)) - the yardstick for an env of the fp64 sweep that leaves 1e-8."""
+    lanes = np.asarray(lanes)
+    L = len(lanes)
+    env_kw = dict(env_kw or {})
+    rows = np.tile(np.arange(L), members)
+    init = np.asarray(init, np.float64)[lanes]
+    toff = None if toffset is None else np.asarray(toffset, np.float64)[lanes]
+    ref = oracle_mod.OracleRovEnv(dof, L, "f64", max_steps=10 ** 9, **env_kw)
+    ens = oracle_mod.OracleRovEnv(dof, L * members, "f64", max_steps=10 ** 9, **env_kw)
+    ref.reset(init, toffset=toff)
+    ens.reset(init[rows], toffset=None if toff is None else toff[rows])
+    ens.noise, ens.noise_seed = float(noise), int(seed)
+    ang = [3, 4, 5] if dof == 6 else [2]
+    dev = np.zeros((len(actions), L))
+    for s in range(len(actions)):
+        a = np.asarray(actions[s], np.float64)[lanes]
+        ref.step(a)
+        ens.step(a[rows])
+        r = np.tile(ref.y, (members, 1))
+        d = np.abs(ens.y - r)
+        d[:, ang] = np.minimum(d[:, ang], np.abs(d[:, ang] - 2 * np.pi))
+        dev[s] = (d / np.maximum(1.0, np.abs(r))).max(axis=1).reshape(members, L).max(axis=0)
+    return dev
+
+
 def make_resolver(oracle_mod, dof, init, actions, env_kw=None, toffset=None):
     """resolver for OutlierAudit.assert_explained: the perturbation ensemble on the run's own inputs."""
     return lambda lanes, steps: ensemble_sensitive(oracle_mod, dof, init, actions, lanes, steps, env_kw, toffset)

@@ -20,6 +20,10 @@ VARIANTS = {
     "f64fulltrig": dict(extra=["-DMVRL_FULL_STAGE_TRIG"], drop=()),
     # round 5, second session: the PID's increment select as it was (six subtract-and-select pairs per first-stage call)
     "notrigvote": dict(extra=["-DMVRL_NO_TRIG_VOTE"], drop=()),   # rare per-lane fall-backs as plain exec guards (before this session: C2 +5 %)
+    # the kernels as they were at the end of the round's first sitting (select forms, exec guards, library expf, fp64 twins with NaN / Inf /
+    # signed-zero bookkeeping): the reference arm when a new seed of a sweep fails - is it this sitting's doing?
+    "r5a": dict(extra=["-DMVRL_INC_SELECT", "-DMVRL_NO_TRIG_VOTE", "-DMVRL_LIB_EXP"], drop=(), f64=["-ffp-contract=fast"]),
+    "noyawwrap": dict(extra=["-DMVRL_NO_YAW_FULL_WRAP"], drop=()),   # the carried yaw error with ONE turn of correction only (rounds 3-5: wrong through gimbal lock)
     "libexp": dict(extra=["-DMVRL_LIB_EXP"], drop=()),   # the 3-DoF jet-drag factors through the library expf (before this session: C2 +18 %)
     "incsel": dict(extra=["-DMVRL_INC_SELECT"], drop=()),
     # fp64 twins: no NaN / Inf / signed-zero bookkeeping, but IEEE division and the written order of operations
