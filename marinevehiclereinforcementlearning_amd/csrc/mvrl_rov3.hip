@@ -45,21 +45,9 @@ __device__ __forceinline__ void control3(PP p, const float* z, Pid3& s, float dt
         const float r1 = s.eold[2] - dpose[2];
         yaw_w = (r1 >= MVRL_PI) ? -MVRL_TWO_PI_HI : ((r1 < -MVRL_PI) ? MVRL_TWO_PI_HI : 0.f);
         e[2] = r1 + yaw_w;
-#ifndef MVRL_NO_YAW_FULL_WRAP
-        // One turn of correction is all the carried error needs - unless the heading moved by more than a full circle within ONE RK stage.
-        // Passing through theta = +-90 deg it does (J2 ~ 1 / cos(theta): Euler-angle rates of 10^2 ... 10^3 rad/s for a stage or two), the
-        // reference's angleError (a fresh reduction at every call, resources.py:75-95) takes that in its stride, and the sign of this
-        // error decides the bang-bang control of the zero-dt stages: found by the fp64 configuration sweep on seeds beyond the suite's
-        // (round 5, second sitting: one env in ~10^5 trajectories of the fixed-set-point x turbulence corner left the fp64 oracle by O(1)
-        // in the step in which cos(theta) changed sign, where the oracle's own sensitivity is 10^2 ... 10^6).  A wave vote; never taken
-        // in an ordinary roll-out.
-        if (__builtin_expect(__any(fabsf(r1) >= 3.f * MVRL_PI) != 0, 0)) {
-            if (fabsf(r1) >= 3.f * MVRL_PI) {
-                e[2] = angle_error(r1, 0.f);
-                yaw_w = e[2] - r1;
-            }
-        }
-#endif
+        // (one turn of correction is all the carried error can need here: the heading rate r is a state of this model - a few rad/s, bounded
+        // by the yaw damping - and moves the heading by h/2 * r << pi per stage.  The 6-DoF model's Euler-angle rates are not bounded that
+        // way: see pid6 in mvrl_rov6.hip.)
     } else {
         e[2] = angle_error(z2, 0.f);
     }

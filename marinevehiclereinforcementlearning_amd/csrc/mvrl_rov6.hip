@@ -97,10 +97,10 @@ __device__ __forceinline__ void pid6(PP p, const float* z, Pid6& s, float half_d
         // One turn of correction is all the carried error needs - unless the heading moved by more than a full circle within ONE RK stage.
         // Passing through theta = +-90 deg it does (J2 ~ 1 / cos(theta): Euler-angle rates of 10^2 ... 10^3 rad/s for a stage or two), the
         // reference's angleError (a fresh reduction at every call, resources.py:75-95) takes that in its stride, and the sign of this
-        // error decides the bang-bang control of the zero-dt stages: found by the fp64 configuration sweep on seeds beyond the suite's
-        // (round 5, second sitting: one env in ~10^5 trajectories of the fixed-set-point x turbulence corner left the fp64 oracle by O(1)
-        // in the step in which cos(theta) changed sign, where the oracle's own sensitivity is 10^2 ... 10^6).  A wave vote; never taken
-        // in an ordinary roll-out.
+        // error decides the bang-bang control of the zero-dt stages.  Rounds 3-5 were a turn short there: found by the fp64 configuration
+        // sweep on seeds beyond the suite's (round 5, second sitting: one env in ~10^5 trajectories of the fixed-set-point x turbulence
+        // corner left the fp64 reference trajectory by O(1) in the step in which cos(theta) changed sign, where that trajectory's own
+        // sensitivity to a perturbation is 10^2 ... 10^6).  A wave vote; never taken in an ordinary roll-out.
         if (__builtin_expect(__any(fabsf(r1) >= 3.f * MVRL_PI) != 0, 0)) {
             if (fabsf(r1) >= 3.f * MVRL_PI) {
                 e[5] = angle_error(r1, 0.f);
